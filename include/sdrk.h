@@ -1,0 +1,161 @@
+/*
+ * sdrk.h — C ABI of the MI355X-native IQ spectrum path ("sdrk" = SDR kernels).
+ *
+ * This is the drop-in boundary of the build.  The reference (a pure-Python Dash
+ * app) has no FFI for this path: the work is three inline numpy expressions in
+ * its SDR reader thread and a deque in its dashboard callback.  Each entry point
+ * below names the reference expression it replaces (paths relative to the
+ * reference checkout):
+ *
+ *   app/sdr/streamer.py:119   fft_data = np.fft.fftshift(np.fft.fft(samples))
+ *   app/sdr/streamer.py:121   power_db = 20 * np.log10(np.abs(fft_data) + 1e-12)
+ *   app/dashboard/callbacks.py:19    waterfall_data = deque(maxlen=100)
+ *   app/dashboard/callbacks.py:176   waterfall_data.append(power_db)
+ *   app/dashboard/callbacks.py:182   waterfall_array = np.array(waterfall_data)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns SDRK_OK (0) or a negative sdrk_status; nothing
+ *     throws; sdrk_last_error() returns a thread-local message for the last
+ *     failure on the calling thread;
+ *   - the caller owns every host buffer; the library owns plans, rings, device
+ *     scratch, pinned staging and streams, released by the matching _destroy;
+ *   - a plan or a waterfall is used by one thread at a time; distinct handles
+ *     (e.g. one per GPU) may be used concurrently from different threads;
+ *   - there is NO CPU fallback behind any of these symbols: with no usable
+ *     gfx950 device they fail with SDRK_ERR_NO_DEVICE.
+ */
+#ifndef SDRK_H
+#define SDRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRK_VERSION 100 /* 0.1.0 */
+
+typedef enum sdrk_status {
+    SDRK_OK = 0,
+    SDRK_ERR_INVALID = -1,     /* bad argument (NULL, size, unsupported nfft …)   */
+    SDRK_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range        */
+    SDRK_ERR_HIP = -3,         /* a HIP runtime call failed; see sdrk_last_error() */
+    SDRK_ERR_NOMEM = -4,       /* host or device allocation failed                 */
+    SDRK_ERR_UNSUPPORTED = -5  /* valid request this build has no kernel for       */
+} sdrk_status;
+
+/* Window applied to each frame before the transform.  The reference applies
+ * none (streamer.py:119): SDRK_WINDOW_RECT reproduces it.  SDRK_WINDOW_HANN is
+ * numpy.hanning(nfft) (symmetric; w[0]=w[nfft-1]=0), the window matplotlib's
+ * psd() uses in scripts/process_sigmf_data.py:188.  SDRK_WINDOW_CUSTOM takes
+ * nfft float32 coefficients from the caller. */
+typedef enum sdrk_window {
+    SDRK_WINDOW_RECT = 0,
+    SDRK_WINDOW_HANN = 1,
+    SDRK_WINDOW_CUSTOM = 2
+} sdrk_window;
+
+typedef struct sdrk_plan sdrk_plan;           /* opaque */
+typedef struct sdrk_waterfall sdrk_waterfall; /* opaque */
+
+/* ---- library / device ---------------------------------------------------- */
+
+int sdrk_version(void);
+/* Thread-local, never NULL; valid until the next failing call on this thread. */
+const char* sdrk_last_error(void);
+/* Number of HIP devices visible to the process (0 if none). */
+int sdrk_device_count(void);
+/* Short device description ("gfx950 … 256 CUs …") into buf. */
+int sdrk_device_info(int device, char* buf, size_t buf_len);
+
+/* ---- device memory helpers (so callers need no other GPU runtime) -------- */
+
+int sdrk_dev_alloc(int device, size_t bytes, void** d_ptr);
+int sdrk_dev_free(int device, void* d_ptr);
+int sdrk_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes);
+int sdrk_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes);
+
+/* ---- spectrum plan -------------------------------------------------------
+ * Replaces streamer.py:119,121 for frames of nfft complex64 samples:
+ *     out_db[k] = 20*log10( | fftshift( fft( w * x ) ) |[k] + eps )     (float32)
+ * nfft: power of two, 2 <= nfft <= 2^22 (2^SDRK_MAX_LOG2_NFFT).
+ * max_batch: largest n_frames a single sdrk_exec_host() call will be given
+ *            (sizes the plan's device staging; exec_device has no such limit).
+ * window_kind / window: see sdrk_window; `window` is read only for CUSTOM.
+ * eps: additive floor on |X| (reference: 1e-12; legacy script 1e-10; 0 allowed).
+ * shift: non-zero = fftshift order (DC at index nfft/2), as the reference. */
+#define SDRK_MAX_LOG2_NFFT 22
+int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind,
+                     const float* window, float eps, int shift, sdrk_plan** out);
+int sdrk_plan_destroy(sdrk_plan* plan);
+int sdrk_plan_nfft(const sdrk_plan* plan);
+int sdrk_plan_device(const sdrk_plan* plan);
+
+/* Host in / host out (the numpy boundary).  iq_c64: interleaved float32 I,Q,
+ * frame f starts at sample f*frame_stride (frame_stride == nfft for packed
+ * frames, == hop for an overlapped STFT over one contiguous stream; the buffer
+ * must hold (n_frames-1)*frame_stride + nfft samples).  out_db: n_frames*nfft
+ * float32, row-major.  Blocks until out_db is complete. */
+int sdrk_exec_host(sdrk_plan* plan, const void* iq_c64, size_t n_frames,
+                   size_t frame_stride, float* out_db);
+
+/* Device in / device out, asynchronous on `stream` (a hipStream_t, or NULL for
+ * the plan's own stream).  Same layout rules as sdrk_exec_host. */
+int sdrk_exec_device(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames,
+                     size_t frame_stride, float* d_out_db, void* stream);
+
+/* Complex spectrum (no |.|, no log): out_c64[f][k] = fft(w*x)[k], optionally
+ * fftshifted as the plan says.  Replaces np.fft.fft at streamer.py:119 alone;
+ * used by the parity tests to check the transform before the log epilogue. */
+int sdrk_exec_fft_host(sdrk_plan* plan, const void* iq_c64, size_t n_frames,
+                       size_t frame_stride, void* out_c64);
+
+/* Block until everything queued on the plan's own stream has finished. */
+int sdrk_plan_sync(sdrk_plan* plan);
+
+/* Timed replay for the bench harness: runs `launches` back-to-back
+ * sdrk_exec_device() calls on the plan's stream bracketed by HIP events on that
+ * stream and returns the elapsed milliseconds (all launches together). */
+int sdrk_exec_device_timed(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames,
+                           size_t frame_stride, float* d_out_db, int launches,
+                           float* elapsed_ms);
+
+/* ---- synthetic IQ generator (bench / parity input, device resident) ------
+ * Sample n of frame F (F = first_frame + f, 64-bit) is
+ *     h = fmix32( fmix32(seed ^ lo32(F)) ^ fmix32(hi32(F) + 0x9E3779B1) ^ n )
+ *     I = (h & 0xFFF) - 2048,  Q = ((h >> 12) & 0xFFF) - 2048      (as float32)
+ * i.e. 12-bit integers like the AD9363 behind streamer.py:114, bit-identical
+ * to the numpy generator in the host package (synth.py). */
+int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_frames,
+                    int nfft, void* d_iq_c64, void* stream);
+
+/* ---- waterfall ring -------------------------------------------------------
+ * Replaces deque(maxlen=100) / append / np.array(deque) at
+ * dashboard/callbacks.py:19,176,182: a device-resident ring of the last
+ * `maxlen` rows of nfft float32, read out oldest row first. */
+int sdrk_waterfall_create(int device, int nfft, int maxlen, sdrk_waterfall** out);
+int sdrk_waterfall_destroy(sdrk_waterfall* wf);
+/* Append n_rows precomputed rows (host float32, n_rows*nfft). */
+int sdrk_waterfall_append_rows(sdrk_waterfall* wf, const float* rows, size_t n_rows);
+/* Transform n_frames host IQ frames with `plan` and append the resulting rows
+ * without a host round trip of the rows (plan nfft/device must match). */
+int sdrk_waterfall_append_iq(sdrk_waterfall* wf, sdrk_plan* plan, const void* iq_c64,
+                             size_t n_frames, size_t frame_stride);
+/* Same, IQ already on the device. */
+int sdrk_waterfall_append_iq_device(sdrk_waterfall* wf, sdrk_plan* plan,
+                                    const void* d_iq_c64, size_t n_frames,
+                                    size_t frame_stride);
+/* Number of valid rows (<= maxlen). */
+int sdrk_waterfall_rows(const sdrk_waterfall* wf);
+/* Copy the valid rows, oldest first, into out (capacity max_rows rows); the
+ * number written is returned through n_rows.  If fewer than rows() fit, the
+ * NEWEST max_rows are returned (still oldest-of-those first). */
+int sdrk_waterfall_read(sdrk_waterfall* wf, float* out, size_t max_rows, size_t* n_rows);
+int sdrk_waterfall_clear(sdrk_waterfall* wf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRK_H */

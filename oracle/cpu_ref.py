@@ -1,0 +1,108 @@
+"""CPU oracle — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A numpy restatement of the reference's streamed-IQ spectrum path, used only as
+the checker in tests/, in ``__graft_entry__.smoke()`` and as the ``cpu_baseline``
+leg of ``bench.py``.  Nothing under ``sdr-iq-visualizer_amd/`` imports it.
+
+Each function cites the reference lines it follows (paths relative to the
+reference checkout).  The arithmetic itself lives in numpy (``numpy.fft`` =
+pocketfft; the reference pins numpy==2.3.2 at requirements.txt:47, this image
+has numpy 2.2.x — both compute complex64 input in single precision).
+
+Pinning: the reference's own tests hold NO golden vectors for this path
+(tests/test_streamer.py patches threading.Thread, so lines
+119-121 never run).  This oracle is therefore pinned against outputs of the
+reference itself, captured by ``oracle/make_golden.py`` (which imports
+``app.sdr.streamer`` with ``adi`` mocked, as the reference's own tests do, and
+drives ``_stream_data``) into ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks this file against them bit for bit.
+"""
+from __future__ import annotations
+
+from collections import deque
+
+import numpy as np
+
+
+def spectrum_db(frames, window=None, eps=1e-12, shift=True):
+    """``power_db`` of app/sdr/streamer.py:119,121, batched over the last axis.
+
+    Expression order is the reference's: fft -> fftshift -> abs -> + eps -> log10
+    -> * 20.  ``window`` (absent in the reference = rectangular) multiplies the
+    samples first, in the input precision.  complex64 in -> float32 out,
+    complex128 in -> float64 out, exactly as numpy does for the reference.
+    """
+    x = np.asarray(frames)
+    if window is not None:
+        w = np.asarray(window)
+        if x.dtype == np.complex64:
+            w = w.astype(np.float32)
+        x = x * w
+    fft_data = np.fft.fft(x, axis=-1)                       # streamer.py:119
+    if shift:
+        fft_data = np.fft.fftshift(fft_data, axes=-1)       # streamer.py:119
+    return 20 * np.log10(np.abs(fft_data) + eps)            # streamer.py:121
+
+
+def fft(frames, window=None, shift=False):
+    """``np.fft.fft`` of streamer.py:119 alone (optionally shifted), same dtype rules."""
+    x = np.asarray(frames)
+    if window is not None:
+        w = np.asarray(window)
+        if x.dtype == np.complex64:
+            w = w.astype(np.float32)
+        x = x * w
+    X = np.fft.fft(x, axis=-1)
+    return np.fft.fftshift(X, axes=-1) if shift else X
+
+
+def freq_axis(n, sample_rate, center_freq):
+    """``freqs`` of app/sdr/streamer.py:120."""
+    return np.fft.fftshift(np.fft.fftfreq(n, 1 / sample_rate)) + center_freq
+
+
+def hann(n):
+    """Symmetric Hann = numpy.hanning(n): the window matplotlib's psd() applies in
+    scripts/process_sigmf_data.py:188 (mlab.window_hanning)."""
+    return np.hanning(n)
+
+
+def stft_db(iq, nfft, hop, window=None, eps=1e-12, shift=True):
+    """Row r = spectrum_db(iq[r*hop : r*hop+nfft]); rows = 1 + (L - nfft)//hop."""
+    iq = np.asarray(iq).reshape(-1)
+    rows = 0 if iq.shape[0] < nfft else 1 + (iq.shape[0] - nfft) // hop
+    out_dtype = np.float32 if iq.dtype == np.complex64 else np.float64
+    out = np.empty((rows, nfft), dtype=out_dtype)
+    for r in range(rows):
+        out[r] = spectrum_db(iq[r * hop: r * hop + nfft], window=window, eps=eps, shift=shift)
+    return out
+
+
+class Waterfall:
+    """app/dashboard/callbacks.py:19,176,182: ``deque(maxlen=100)``, ``append(power_db)``,
+    ``np.array(deque)`` — rows oldest first; y axis = range(len) (:186)."""
+
+    def __init__(self, maxlen=100):
+        self.rows = deque(maxlen=maxlen)                     # callbacks.py:19
+
+    def append(self, power_db):
+        self.rows.append(power_db)                           # callbacks.py:176
+
+    def __len__(self):
+        return len(self.rows)
+
+    def as_array(self):
+        return np.array(self.rows)                           # callbacks.py:182
+
+
+def process_frame(samples, sample_rate, center_freq, now=None):
+    """The ``plot_data`` dict of app/sdr/streamer.py:119-130."""
+    import time
+    return {
+        "time": time.time() if now is None else now,
+        "samples": samples,
+        "freqs": freq_axis(len(samples), sample_rate, center_freq),
+        "power_db": spectrum_db(samples),
+        "sample_rate": sample_rate,
+        "center_freq": center_freq,
+    }

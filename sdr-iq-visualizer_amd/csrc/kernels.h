@@ -1,0 +1,49 @@
+// kernels.h — internal interface between the C ABI (sdrk_api.hip) and the
+// gfx950 kernels.  Nothing here is exported from the shared library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace sdrk {
+
+enum Epilogue : int {
+    EPI_LOGPSD = 0,   // float32 20*log10(|X| + eps)          (streamer.py:121)
+    EPI_COMPLEX = 1,  // complex64 X                           (streamer.py:119 only)
+};
+
+struct LaunchArgs {
+    const void* d_iq = nullptr;        // complex64, frame f at sample f*frame_stride
+    size_t frame_stride = 0;           // samples between frame starts
+    void* d_out = nullptr;             // float32[n_frames][nfft] or complex64[...]
+    size_t n_frames = 0;
+    int nfft = 0;
+    const float* d_window = nullptr;   // nfft floats or nullptr (rectangular)
+    const void* d_twiddle = nullptr;   // complex64 W_nfft^m, m in [0,nfft) (or [0,4096) for big plans)
+    float eps = 1e-12f;
+    int shift = 1;
+    int epilogue = EPI_LOGPSD;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    void* d_scratch = nullptr;         // large-N plans: complex64 scratch, scratch_frames*nfft
+    size_t scratch_frames = 0;
+    const void* d_twiddle_big = nullptr;  // large-N plans: coarse/fine tables for W_nfft
+};
+
+// 20*log10(sqrt(re^2+im^2) + eps), the expression order of streamer.py:121:
+// |X| first, then the additive floor, then the log.  v_sqrt_f32 / v_log_f32 are
+// 1-ulp approximations; the result is within ~2e-5 dB of numpy's float32 path
+// over the float32 range (checked by tests/test_parity_gpu.py).
+__device__ __forceinline__ float logpsd_db(float re, float im, float eps) {
+    float p = fmaf(re, re, im * im);
+    float mag = __builtin_amdgcn_sqrtf(p);
+    return __builtin_amdgcn_logf(mag + eps) * 6.02059991327962390427f;  // log2 -> 20*log10
+}
+
+hipError_t launch_fft4096(const LaunchArgs& a);
+hipError_t launch_fft_small(const LaunchArgs& a);   // 2 <= nfft <= 2048 (and 4096 for A/B)
+hipError_t launch_fft_large(const LaunchArgs& a);   // nfft > 4096 (multi-pass)
+hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,
+                             void* d_iq, hipStream_t stream);
+
+}  // namespace sdrk

@@ -1,0 +1,545 @@
+// sdrk_api.hip — host side of the C ABI declared in include/sdrk.h: plans,
+// device staging, the waterfall ring, error reporting.  All compute is in the
+// gfx950 kernels (fft4096.hip, fft_small.hip, fft_large.hip, aux_kernels.hip);
+// there is no host fallback anywhere in this file.
+#include "../../include/sdrk.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return fail(e__ == hipErrorOutOfMemory ? SDRK_ERR_NOMEM : SDRK_ERR_HIP,        \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,  \
+                        __LINE__);                                                         \
+    } while (0)
+
+int check_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(SDRK_ERR_NO_DEVICE, "no HIP device available (%s)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    if (device < 0 || device >= n)
+        return fail(SDRK_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    return SDRK_OK;
+}
+
+bool is_pow2(long long v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// exp(-2 pi i m / n) in double, rounded once to float32.
+float2 twiddle(double m, double n) {
+    const double a = -2.0 * M_PI * m / n;
+    return make_float2((float)std::cos(a), (float)std::sin(a));
+}
+
+}  // namespace
+
+struct sdrk_plan {
+    int device = 0;
+    int nfft = 0;
+    size_t max_batch = 0;
+    float eps = 1e-12f;
+    int shift = 1;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float* d_window = nullptr;     // nfft floats, or nullptr for rectangular
+    float2* d_twiddle = nullptr;   // W_min(nfft,4096)^m
+    float2* d_tw_big = nullptr;    // large plans: coarse[1024] then fine[4096]
+    float2* d_scratch = nullptr;   // large plans
+    size_t scratch_frames = 0;
+    void* d_in = nullptr;          // staging for sdrk_exec_host (grown on demand)
+    size_t in_cap = 0;
+    void* d_out = nullptr;
+    size_t out_cap = 0;
+};
+
+struct sdrk_waterfall {
+    int device = 0;
+    int nfft = 0;
+    int maxlen = 0;
+    float* d_ring = nullptr;  // maxlen * nfft float32
+    size_t head = 0;          // slot the next row is written to
+    size_t count = 0;         // valid rows (<= maxlen)
+    hipStream_t stream = nullptr;
+};
+
+namespace {
+
+int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
+                int epilogue, hipStream_t stream) {
+    sdrk::LaunchArgs a;
+    a.d_iq = d_iq;
+    a.frame_stride = frame_stride;
+    a.d_out = d_out;
+    a.n_frames = n_frames;
+    a.nfft = p->nfft;
+    a.d_window = p->d_window;
+    a.d_twiddle = p->d_twiddle;
+    a.eps = p->eps;
+    a.shift = p->shift;
+    a.epilogue = epilogue;
+    a.stream = stream;
+    a.num_cus = p->num_cus;
+    a.d_scratch = p->d_scratch;
+    a.scratch_frames = p->scratch_frames;
+    a.d_twiddle_big = p->d_tw_big;
+    hipError_t e;
+    if (p->nfft == 4096)
+        e = sdrk::launch_fft4096(a);
+    else if (p->nfft < 4096)
+        e = sdrk::launch_fft_small(a);
+    else
+        e = sdrk::launch_fft_large(a);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return SDRK_OK;
+}
+
+int check_exec_args(const sdrk_plan* p, const void* in, size_t n_frames, size_t frame_stride,
+                    const void* out) {
+    if (!p) return fail(SDRK_ERR_INVALID, "plan is NULL");
+    if (n_frames == 0) return SDRK_OK;
+    if (!in || !out) return fail(SDRK_ERR_INVALID, "input or output pointer is NULL");
+    if (frame_stride == 0 && n_frames > 1)
+        return fail(SDRK_ERR_INVALID, "frame_stride must be >= 1 for more than one frame");
+    return SDRK_OK;
+}
+
+int grow(int device, void** buf, size_t* cap, size_t need) {
+    if (need <= *cap) return SDRK_OK;
+    if (*buf) {
+        HIP_TRY(hipFree(*buf));
+        *buf = nullptr;
+        *cap = 0;
+    }
+    HIP_TRY(hipMalloc(buf, need));
+    *cap = need;
+    (void)device;
+    return SDRK_OK;
+}
+
+int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride, void* out,
+                     int epilogue) {
+    int st = check_exec_args(p, iq, n_frames, frame_stride, out);
+    if (st != SDRK_OK || n_frames == 0) return st;
+    if (n_frames > p->max_batch)
+        return fail(SDRK_ERR_INVALID, "n_frames %zu exceeds the plan's max_batch %zu", n_frames,
+                    p->max_batch);
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t in_samples = (n_frames - 1) * frame_stride + (size_t)p->nfft;
+    const size_t in_bytes = in_samples * sizeof(float2);
+    const size_t out_elem = epilogue == sdrk::EPI_LOGPSD ? sizeof(float) : sizeof(float2);
+    const size_t out_bytes = n_frames * (size_t)p->nfft * out_elem;
+    st = grow(p->device, &p->d_in, &p->in_cap, in_bytes);
+    if (st != SDRK_OK) return st;
+    st = grow(p->device, &p->d_out, &p->out_cap, out_bytes);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
+    st = plan_launch(p, p->d_in, n_frames, frame_stride, p->d_out, epilogue, p->stream);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SDRK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdrk_version(void) { return SDRK_VERSION; }
+
+const char* sdrk_last_error(void) { return g_last_error.c_str(); }
+
+int sdrk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int sdrk_device_info(int device, char* buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return fail(SDRK_ERR_INVALID, "buf is NULL/empty");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buf_len, "%s %s, %d CUs, %.1f GiB, %d MHz", prop.gcnArchName, prop.name,
+             prop.multiProcessorCount, (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0),
+             prop.clockRate / 1000);
+    return SDRK_OK;
+}
+
+int sdrk_dev_alloc(int device, size_t bytes, void** d_ptr) {
+    if (!d_ptr) return fail(SDRK_ERR_INVALID, "d_ptr is NULL");
+    *d_ptr = nullptr;
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return SDRK_OK;
+}
+
+int sdrk_dev_free(int device, void* d_ptr) {
+    if (!d_ptr) return SDRK_OK;
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(d_ptr));
+    return SDRK_OK;
+}
+
+int sdrk_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes) {
+    if (bytes == 0) return SDRK_OK;
+    if (!d_dst || !h_src) return fail(SDRK_ERR_INVALID, "NULL pointer");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return SDRK_OK;
+}
+
+int sdrk_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return SDRK_OK;
+    if (!h_dst || !d_src) return fail(SDRK_ERR_INVALID, "NULL pointer");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return SDRK_OK;
+}
+
+int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, const float* window,
+                     float eps, int shift, sdrk_plan** out) {
+    if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (nfft < 2 || !is_pow2(nfft) || nfft > (1 << SDRK_MAX_LOG2_NFFT))
+        return fail(SDRK_ERR_INVALID, "nfft=%d: must be a power of two in [2, 2^%d]", nfft,
+                    SDRK_MAX_LOG2_NFFT);
+    if (max_batch == 0) return fail(SDRK_ERR_INVALID, "max_batch must be >= 1");
+    if (window_kind < SDRK_WINDOW_RECT || window_kind > SDRK_WINDOW_CUSTOM)
+        return fail(SDRK_ERR_INVALID, "unknown window_kind %d", window_kind);
+    if (window_kind == SDRK_WINDOW_CUSTOM && !window)
+        return fail(SDRK_ERR_INVALID, "SDRK_WINDOW_CUSTOM needs a window pointer");
+    if (!(eps >= 0.0f)) return fail(SDRK_ERR_INVALID, "eps must be >= 0");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SDRK_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                    device, prop.gcnArchName);
+
+    sdrk_plan* p = new (std::nothrow) sdrk_plan();
+    if (!p) return fail(SDRK_ERR_NOMEM, "out of host memory");
+    p->device = device;
+    p->nfft = nfft;
+    p->max_batch = max_batch;
+    p->eps = eps;
+    p->shift = shift ? 1 : 0;
+    p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+#define PLAN_TRY(expr)                                                                     \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            int s__ = fail(e__ == hipErrorOutOfMemory ? SDRK_ERR_NOMEM : SDRK_ERR_HIP,     \
+                           "%s failed: %s", #expr, hipGetErrorString(e__));                \
+            sdrk_plan_destroy(p);                                                          \
+            return s__;                                                                    \
+        }                                                                                  \
+    } while (0)
+
+    PLAN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    PLAN_TRY(hipEventCreate(&p->ev0));
+    PLAN_TRY(hipEventCreate(&p->ev1));
+
+    // window
+    if (window_kind != SDRK_WINDOW_RECT) {
+        std::vector<float> w(nfft);
+        if (window_kind == SDRK_WINDOW_HANN) {
+            // numpy.hanning(M): 0.5 - 0.5 cos(2 pi n / (M-1)); M == 1 would be [1.0]
+            for (int n = 0; n < nfft; ++n)
+                w[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)(nfft - 1)));
+        } else {
+            memcpy(w.data(), window, sizeof(float) * nfft);
+        }
+        PLAN_TRY(hipMalloc((void**)&p->d_window, sizeof(float) * nfft));
+        PLAN_TRY(hipMemcpy(p->d_window, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice));
+    }
+    // twiddles of the in-LDS transform
+    {
+        const int tn = nfft < 4096 ? nfft : 4096;
+        std::vector<float2> t(tn);
+        for (int m = 0; m < tn; ++m) t[m] = twiddle(m, tn);
+        PLAN_TRY(hipMalloc((void**)&p->d_twiddle, sizeof(float2) * tn));
+        PLAN_TRY(hipMemcpy(p->d_twiddle, t.data(), sizeof(float2) * tn, hipMemcpyHostToDevice));
+    }
+    if (nfft > 4096) {
+        const int n1 = nfft / 4096;
+        std::vector<float2> t(1024 + 4096);
+        for (int m = 0; m < 1024; ++m) t[m] = twiddle(m % n1, n1);           // coarse: W_N1^m = W_N^(4096 m)
+        for (int m = 0; m < 4096; ++m) t[1024 + m] = twiddle(m, (double)nfft);  // fine: W_N^m
+        PLAN_TRY(hipMalloc((void**)&p->d_tw_big, sizeof(float2) * t.size()));
+        PLAN_TRY(hipMemcpy(p->d_tw_big, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
+        // scratch: up to 128 MiB of complex64 frames (stays in the 256 MiB Infinity Cache)
+        size_t frames = ((size_t)128 << 20) / ((size_t)nfft * sizeof(float2));
+        if (frames < 1) frames = 1;
+        if (frames > max_batch) frames = max_batch;
+        p->scratch_frames = frames;
+        PLAN_TRY(hipMalloc((void**)&p->d_scratch, frames * (size_t)nfft * sizeof(float2)));
+    }
+#undef PLAN_TRY
+    *out = p;
+    return SDRK_OK;
+}
+
+int sdrk_plan_destroy(sdrk_plan* p) {
+    if (!p) return SDRK_OK;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->d_window) (void)hipFree(p->d_window);
+    if (p->d_twiddle) (void)hipFree(p->d_twiddle);
+    if (p->d_tw_big) (void)hipFree(p->d_tw_big);
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_in) (void)hipFree(p->d_in);
+    if (p->d_out) (void)hipFree(p->d_out);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return SDRK_OK;
+}
+
+int sdrk_plan_nfft(const sdrk_plan* p) { return p ? p->nfft : fail(SDRK_ERR_INVALID, "plan is NULL"); }
+int sdrk_plan_device(const sdrk_plan* p) { return p ? p->device : fail(SDRK_ERR_INVALID, "plan is NULL"); }
+
+int sdrk_exec_host(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride, float* out_db) {
+    return exec_host_common(p, iq, n_frames, frame_stride, out_db, sdrk::EPI_LOGPSD);
+}
+
+int sdrk_exec_fft_host(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride,
+                       void* out_c64) {
+    return exec_host_common(p, iq, n_frames, frame_stride, out_c64, sdrk::EPI_COMPLEX);
+}
+
+int sdrk_exec_device(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride,
+                     float* d_out_db, void* stream) {
+    int st = check_exec_args(p, d_iq, n_frames, frame_stride, d_out_db);
+    if (st != SDRK_OK || n_frames == 0) return st;
+    HIP_TRY(hipSetDevice(p->device));
+    return plan_launch(p, d_iq, n_frames, frame_stride, d_out_db, sdrk::EPI_LOGPSD,
+                       stream ? static_cast<hipStream_t>(stream) : p->stream);
+}
+
+int sdrk_plan_sync(sdrk_plan* p) {
+    if (!p) return fail(SDRK_ERR_INVALID, "plan is NULL");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SDRK_OK;
+}
+
+int sdrk_exec_device_timed(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride,
+                           float* d_out_db, int launches, float* elapsed_ms) {
+    if (!elapsed_ms || launches < 1) return fail(SDRK_ERR_INVALID, "bad launches/elapsed_ms");
+    int st = check_exec_args(p, d_iq, n_frames, frame_stride, d_out_db);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    for (int i = 0; i < launches; ++i) {
+        st = plan_launch(p, d_iq, n_frames, frame_stride, d_out_db, sdrk::EPI_LOGPSD, p->stream);
+        if (st != SDRK_OK) return st;
+    }
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    HIP_TRY(hipEventSynchronize(p->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, p->ev0, p->ev1));
+    return SDRK_OK;
+}
+
+int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,
+                    void* d_iq, void* stream) {
+    if (n_frames == 0) return SDRK_OK;
+    if (!d_iq) return fail(SDRK_ERR_INVALID, "d_iq is NULL");
+    if (nfft < 2 || (nfft & 1)) return fail(SDRK_ERR_INVALID, "nfft must be even and >= 2");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = sdrk::launch_synth_fill(seed, first_frame, n_frames, nfft, d_iq, s);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "synth launch failed: %s", hipGetErrorString(e));
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return SDRK_OK;
+}
+
+/* ---- waterfall ring ------------------------------------------------------ */
+
+int sdrk_waterfall_create(int device, int nfft, int maxlen, sdrk_waterfall** out) {
+    if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (nfft < 1) return fail(SDRK_ERR_INVALID, "nfft must be >= 1");
+    if (maxlen < 1) return fail(SDRK_ERR_INVALID, "maxlen must be >= 1");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    sdrk_waterfall* wf = new (std::nothrow) sdrk_waterfall();
+    if (!wf) return fail(SDRK_ERR_NOMEM, "out of host memory");
+    wf->device = device;
+    wf->nfft = nfft;
+    wf->maxlen = maxlen;
+    hipError_t e = hipMalloc((void**)&wf->d_ring, (size_t)maxlen * nfft * sizeof(float));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&wf->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        int s = fail(e == hipErrorOutOfMemory ? SDRK_ERR_NOMEM : SDRK_ERR_HIP,
+                     "waterfall allocation failed: %s", hipGetErrorString(e));
+        sdrk_waterfall_destroy(wf);
+        return s;
+    }
+    *out = wf;
+    return SDRK_OK;
+}
+
+int sdrk_waterfall_destroy(sdrk_waterfall* wf) {
+    if (!wf) return SDRK_OK;
+    (void)hipSetDevice(wf->device);
+    if (wf->stream) {
+        (void)hipStreamSynchronize(wf->stream);
+        (void)hipStreamDestroy(wf->stream);
+    }
+    if (wf->d_ring) (void)hipFree(wf->d_ring);
+    delete wf;
+    return SDRK_OK;
+}
+
+int sdrk_waterfall_rows(const sdrk_waterfall* wf) {
+    return wf ? (int)wf->count : fail(SDRK_ERR_INVALID, "waterfall is NULL");
+}
+
+int sdrk_waterfall_clear(sdrk_waterfall* wf) {
+    if (!wf) return fail(SDRK_ERR_INVALID, "waterfall is NULL");
+    wf->head = 0;
+    wf->count = 0;
+    return SDRK_OK;
+}
+
+static void wf_advance(sdrk_waterfall* wf, size_t rows) {
+    wf->head = (wf->head + rows) % (size_t)wf->maxlen;
+    wf->count = wf->count + rows > (size_t)wf->maxlen ? (size_t)wf->maxlen : wf->count + rows;
+}
+
+int sdrk_waterfall_append_rows(sdrk_waterfall* wf, const float* rows, size_t n_rows) {
+    if (!wf) return fail(SDRK_ERR_INVALID, "waterfall is NULL");
+    if (n_rows == 0) return SDRK_OK;
+    if (!rows) return fail(SDRK_ERR_INVALID, "rows is NULL");
+    HIP_TRY(hipSetDevice(wf->device));
+    // deque(maxlen) semantics (dashboard/callbacks.py:19,176): only the newest maxlen survive.
+    size_t skip = n_rows > (size_t)wf->maxlen ? n_rows - (size_t)wf->maxlen : 0;
+    if (skip) wf_advance(wf, skip);
+    const size_t row_bytes = (size_t)wf->nfft * sizeof(float);
+    size_t done = skip;
+    while (done < n_rows) {
+        size_t run = (size_t)wf->maxlen - wf->head;
+        if (run > n_rows - done) run = n_rows - done;
+        HIP_TRY(hipMemcpyAsync(wf->d_ring + wf->head * (size_t)wf->nfft, rows + done * (size_t)wf->nfft,
+                               run * row_bytes, hipMemcpyHostToDevice, wf->stream));
+        wf_advance(wf, run);
+        done += run;
+    }
+    HIP_TRY(hipStreamSynchronize(wf->stream));
+    return SDRK_OK;
+}
+
+int sdrk_waterfall_append_iq_device(sdrk_waterfall* wf, sdrk_plan* p, const void* d_iq,
+                                    size_t n_frames, size_t frame_stride) {
+    if (!wf || !p) return fail(SDRK_ERR_INVALID, "waterfall or plan is NULL");
+    if (p->nfft != wf->nfft || p->device != wf->device)
+        return fail(SDRK_ERR_INVALID, "plan (nfft %d, device %d) does not match waterfall (nfft %d, device %d)",
+                    p->nfft, p->device, wf->nfft, wf->device);
+    if (n_frames == 0) return SDRK_OK;
+    if (!d_iq) return fail(SDRK_ERR_INVALID, "d_iq is NULL");
+    HIP_TRY(hipSetDevice(wf->device));
+    size_t skip = n_frames > (size_t)wf->maxlen ? n_frames - (size_t)wf->maxlen : 0;
+    if (skip) wf_advance(wf, skip);
+    size_t done = skip;
+    while (done < n_frames) {
+        size_t run = (size_t)wf->maxlen - wf->head;
+        if (run > n_frames - done) run = n_frames - done;
+        // the transform writes its rows straight into the ring slots
+        int st = plan_launch(p, static_cast<const float2*>(d_iq) + done * frame_stride, run, frame_stride,
+                             wf->d_ring + wf->head * (size_t)wf->nfft, sdrk::EPI_LOGPSD, wf->stream);
+        if (st != SDRK_OK) return st;
+        wf_advance(wf, run);
+        done += run;
+    }
+    HIP_TRY(hipStreamSynchronize(wf->stream));
+    return SDRK_OK;
+}
+
+int sdrk_waterfall_append_iq(sdrk_waterfall* wf, sdrk_plan* p, const void* iq, size_t n_frames,
+                             size_t frame_stride) {
+    if (!wf || !p) return fail(SDRK_ERR_INVALID, "waterfall or plan is NULL");
+    if (n_frames == 0) return SDRK_OK;
+    if (!iq) return fail(SDRK_ERR_INVALID, "iq is NULL");
+    if (frame_stride == 0 && n_frames > 1) return fail(SDRK_ERR_INVALID, "frame_stride must be >= 1");
+    if (n_frames > p->max_batch)
+        return fail(SDRK_ERR_INVALID, "n_frames %zu exceeds the plan's max_batch %zu", n_frames, p->max_batch);
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t in_bytes = ((n_frames - 1) * frame_stride + (size_t)p->nfft) * sizeof(float2);
+    int st = grow(p->device, &p->d_in, &p->in_cap, in_bytes);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, wf->stream));
+    return sdrk_waterfall_append_iq_device(wf, p, p->d_in, n_frames, frame_stride);
+}
+
+int sdrk_waterfall_read(sdrk_waterfall* wf, float* out, size_t max_rows, size_t* n_rows) {
+    if (!wf || !n_rows) return fail(SDRK_ERR_INVALID, "waterfall or n_rows is NULL");
+    *n_rows = 0;
+    size_t rows = wf->count < max_rows ? wf->count : max_rows;
+    if (rows == 0) return SDRK_OK;
+    if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
+    HIP_TRY(hipSetDevice(wf->device));
+    const size_t L = (size_t)wf->maxlen, nf = (size_t)wf->nfft;
+    // newest row is at head-1; the `rows` newest start at head-rows (mod L)
+    size_t start = (wf->head + L - rows % L) % L;
+    size_t first = L - start < rows ? L - start : rows;
+    HIP_TRY(hipMemcpyAsync(out, wf->d_ring + start * nf, first * nf * sizeof(float),
+                           hipMemcpyDeviceToHost, wf->stream));
+    if (first < rows)
+        HIP_TRY(hipMemcpyAsync(out + first * nf, wf->d_ring, (rows - first) * nf * sizeof(float),
+                               hipMemcpyDeviceToHost, wf->stream));
+    HIP_TRY(hipStreamSynchronize(wf->stream));
+    *n_rows = rows;
+    return SDRK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""Frame-range sharding of a batch across the GPUs of one node — no collectives.
+
+Every frame is independent at the reference's call site (app/sdr/streamer.py:
+119-121: one FFT per hardware buffer, no state carried between frames), so a
+batch partitions into contiguous frame ranges, one per GPU, and the only
+"exchange" is the host gathering each range's rows into one array.  Two ways to
+drive it:
+
+* ``spectrum_db_sharded`` — one process, one Python thread per device (ctypes
+  releases the GIL during the C call), each thread writing its slice of a shared
+  output array;
+* ``distributed_spectrum_db`` — one process per GPU under ``torch.distributed``
+  (launched by torchrun; backend "nccl" is RCCL on ROCm, "gloo" on CPU hosts):
+  each rank transforms its own range and rank ``dst`` gathers the rows.
+
+RCCL over xGMI would only enter if a cross-frame reduction (Welch mean, max-hold)
+were added; the path as the reference defines it has none.
+"""
+from __future__ import annotations
+
+import threading
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def shard_ranges(n_frames: int, n_shards: int) -> List[Tuple[int, int]]:
+    """Contiguous ``[start, stop)`` ranges covering ``n_frames``; the first
+    ``n_frames % n_shards`` shards get one extra frame; empty shards are allowed."""
+    if n_shards < 1:
+        raise ValueError("n_shards must be >= 1")
+    if n_frames < 0:
+        raise ValueError("n_frames must be >= 0")
+    base, extra = divmod(n_frames, n_shards)
+    out, start = [], 0
+    for s in range(n_shards):
+        stop = start + base + (1 if s < extra else 0)
+        out.append((start, stop))
+        start = stop
+    return out
+
+
+def rank_range(n_frames: int, rank: int, world_size: int) -> Tuple[int, int]:
+    return shard_ranges(n_frames, world_size)[rank]
+
+
+def spectrum_db_sharded(samples, devices: Sequence[int], *, window=None, eps: float = 1e-12,
+                        shift: bool = True) -> np.ndarray:
+    """``spectrum_db`` of a ``(B, N)`` batch split over ``devices`` by frame range."""
+    from .spectrum import _as_c64, _cached_plan
+
+    x = _as_c64(samples)
+    if x.ndim != 2:
+        raise ValueError("sharding needs a (B, N) batch")
+    out = np.empty(x.shape, dtype=np.float32)
+    ranges = shard_ranges(x.shape[0], len(devices))
+    errors: List[BaseException] = []
+
+    def work(dev: int, lo: int, hi: int) -> None:
+        try:
+            if hi > lo:
+                out[lo:hi] = _cached_plan(x.shape[1], window, eps, shift, dev).spectrum_db(x[lo:hi])
+        except BaseException as e:  # surfaced on the calling thread below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(d, lo, hi)) for d, (lo, hi) in zip(devices, ranges)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def _default_compute(window, eps, shift, device) -> Callable[[np.ndarray], np.ndarray]:
+    from .spectrum import _cached_plan
+
+    def compute(frames: np.ndarray) -> np.ndarray:
+        return _cached_plan(frames.shape[1], window, eps, shift, device).spectrum_db(frames)
+
+    return compute
+
+
+def distributed_spectrum_db(samples, *, window=None, eps: float = 1e-12, shift: bool = True,
+                            device: Optional[int] = None, dst: int = 0, group=None,
+                            compute: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+    """One-process-per-GPU form.  Every rank passes the same ``(B, N)`` batch (or a
+    lazily-indexable view of it); rank r transforms frames ``rank_range(B, r, W)``
+    on its own GPU and rank ``dst`` returns the gathered ``(B, N)`` float32 array
+    (other ranks return ``None``).  ``compute`` replaces the per-rank transform —
+    the CPU test-suite injects the oracle there to exercise the sharding and the
+    gather under gloo without a GPU; the product default is the HIP path."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n_frames, nfft = int(samples.shape[0]), int(samples.shape[1])
+    lo, hi = rank_range(n_frames, rank, world)
+    if compute is None:
+        if device is None:
+            import os
+            device = int(os.environ.get("LOCAL_RANK", rank))
+        compute = _default_compute(window, eps, shift, device)
+    mine = np.ascontiguousarray(samples[lo:hi])
+    rows = compute(mine) if hi > lo else np.empty((0, nfft), dtype=np.float32)
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+
+    # Host gather: pad every shard to the longest range so one gather suffices.
+    longest = max(b - a for a, b in shard_ranges(n_frames, world))
+    padded = np.zeros((longest, nfft), dtype=np.float32)
+    padded[: hi - lo] = rows
+    use_cuda = dist.get_backend(group) == "nccl"
+    t = torch.from_numpy(padded)
+    if use_cuda:
+        t = t.cuda()
+    bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+    dist.gather(t, bucket, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = np.empty((n_frames, nfft), dtype=np.float32)
+    for r, (a, b) in enumerate(shard_ranges(n_frames, world)):
+        out[a:b] = bucket[r][: b - a].cpu().numpy()
+    return out

@@ -1,0 +1,291 @@
+"""numpy-in / numpy-out spectrum functions backed by the gfx950 kernels.
+
+This module is the host-side mirror of the reference's hot path.  The reference
+has no function boundary there — it is three inline expressions in the SDR
+reader thread — so the functions below *are* the boundary a maintainer would
+call from those lines:
+
+    app/sdr/streamer.py:119  fft_data = np.fft.fftshift(np.fft.fft(samples))
+    app/sdr/streamer.py:120  freqs = np.fft.fftshift(np.fft.fftfreq(len(samples), 1/self.sample_rate)) + self.center_freq
+    app/sdr/streamer.py:121  power_db = 20 * np.log10(np.abs(fft_data) + 1e-12)
+    app/sdr/streamer.py:123-130  plot_data = {...}
+
+Defaults reproduce the reference exactly: rectangular window, un-normalised
+forward DFT, fftshift, additive floor 1e-12 on |X|.  Contract: complex64 in,
+float32 out (complex128 input is down-cast; the reference would then compute in
+float64 — documented difference, well inside the 1e-5 parity bar).
+
+All arithmetic on samples happens on the GPU through ``libsdrk.so``; nothing in
+this module computes a spectrum with numpy, and every entry point raises if the
+library or a device is missing.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import byref, c_float, c_size_t, c_void_p, check, lib
+
+WindowArg = Union[None, str, np.ndarray, Sequence[float]]
+
+# One sdrk_exec_host call stages its whole input on the device; larger host
+# batches are fed through in chunks of about this many input bytes.
+_HOST_CHUNK_BYTES = 256 << 20
+
+
+def _window_spec(window: WindowArg, nfft: int):
+    """-> (kind, float32 array or None, cache key)."""
+    if window is None:
+        return _ffi.WINDOW_RECT, None, "rect"
+    if isinstance(window, str):
+        name = window.lower()
+        if name in ("rect", "rectangular", "boxcar", "none"):
+            return _ffi.WINDOW_RECT, None, "rect"
+        if name in ("hann", "hanning"):
+            return _ffi.WINDOW_HANN, None, "hann"
+        raise ValueError(f"unknown window {window!r} (use None, 'hann' or an array of nfft floats)")
+    w = np.ascontiguousarray(np.asarray(window, dtype=np.float32))
+    if w.ndim != 1 or w.shape[0] != nfft:
+        raise ValueError(f"window must have shape ({nfft},), got {w.shape}")
+    return _ffi.WINDOW_CUSTOM, w, ("custom", w.tobytes())
+
+
+def _as_c64(a) -> np.ndarray:
+    """complex64, C-contiguous view or copy of `a` (down-casts complex128)."""
+    arr = np.asarray(a)
+    if arr.dtype != np.complex64:
+        arr = arr.astype(np.complex64)
+    return np.ascontiguousarray(arr)
+
+
+class SpectrumPlan:
+    """A compiled plan for one (nfft, window, eps, shift, device) combination.
+
+    Thin owner of an ``sdrk_plan``; methods take and return numpy arrays.  A plan
+    is used by one thread at a time (an internal lock enforces it); create one
+    plan per device to drive several GPUs from several threads.
+    """
+
+    def __init__(self, nfft: int, *, window: WindowArg = None, eps: float = 1e-12,
+                 shift: bool = True, device: int = 0, max_batch: int = 1 << 30):
+        nfft = int(nfft)
+        if nfft < 2 or nfft & (nfft - 1) or nfft > (1 << _ffi.MAX_LOG2_NFFT):
+            raise ValueError(
+                f"nfft={nfft}: this build transforms power-of-two frames in [2, 2^{_ffi.MAX_LOG2_NFFT}]")
+        kind, warr, self._wkey = _window_spec(window, nfft)
+        _ffi.require_device(device)
+        self.nfft = nfft
+        self.eps = float(eps)
+        self.shift = bool(shift)
+        self.device = int(device)
+        self._lock = threading.Lock()
+        self._handle = c_void_p()
+        wptr = warr.ctypes.data_as(c_void_p) if warr is not None else None
+        check(lib().sdrk_plan_create(self.device, nfft, c_size_t(int(max_batch)), kind, wptr,
+                                     c_float(self.eps), int(self.shift), byref(self._handle)))
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self) -> None:
+        h, self._handle = self._handle, c_void_p()
+        if h:
+            lib().sdrk_plan_destroy(h)
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self) -> c_void_p:
+        if not self._handle:
+            raise RuntimeError("plan is closed")
+        return self._handle
+
+    # -- host arrays ------------------------------------------------------------
+    def _run_host(self, fn, iq: np.ndarray, n_frames: int, stride: int, out: np.ndarray) -> None:
+        """Feed `n_frames` frames (start spacing `stride` samples) through `fn` in chunks."""
+        nfft = self.nfft
+        per = max(1, min(_HOST_CHUNK_BYTES // (8 * max(stride, 1)), _HOST_CHUNK_BYTES // (4 * nfft)))
+        flat_in = iq.reshape(-1)
+        flat_out = out.reshape(n_frames, nfft)
+        with self._lock:
+            f0 = 0
+            while f0 < n_frames:
+                nf = min(per, n_frames - f0)
+                src = flat_in[f0 * stride:]
+                dst = flat_out[f0:f0 + nf]
+                check(fn(self.handle, src.ctypes.data_as(c_void_p), c_size_t(nf), c_size_t(stride),
+                         dst.ctypes.data_as(c_void_p)))
+                f0 += nf
+
+    def _frames(self, samples):
+        x = _as_c64(samples)
+        if x.ndim == 1:
+            if x.shape[0] != self.nfft:
+                raise ValueError(f"frame has {x.shape[0]} samples, plan nfft is {self.nfft}")
+            return x.reshape(1, -1), True
+        if x.ndim != 2 or x.shape[1] != self.nfft:
+            raise ValueError(f"expected shape ({self.nfft},) or (B, {self.nfft}), got {x.shape}")
+        return x, False
+
+    def spectrum_db(self, samples) -> np.ndarray:
+        """float32 ``20*log10(|fftshift(fft(w*x))| + eps)`` for one frame or a batch."""
+        x, one = self._frames(samples)
+        out = np.empty(x.shape, dtype=np.float32)
+        if x.shape[0]:
+            self._run_host(lib().sdrk_exec_host, x, x.shape[0], self.nfft, out)
+        return out[0] if one else out
+
+    def fft(self, samples) -> np.ndarray:
+        """complex64 spectrum ``fft(w*x)`` (fftshifted if the plan shifts), no log."""
+        x, one = self._frames(samples)
+        out = np.empty(x.shape, dtype=np.complex64)
+        if x.shape[0]:
+            self._run_host(lib().sdrk_exec_fft_host, x, x.shape[0], self.nfft, out)
+        return out[0] if one else out
+
+    def stft_db(self, iq, hop: Optional[int] = None) -> np.ndarray:
+        """Rows of a spectrogram over one contiguous stream: row r covers samples
+        ``[r*hop, r*hop + nfft)``; ``rows = 1 + (len(iq) - nfft) // hop`` (0 if the
+        stream is shorter than one frame).  Frames are cut on the device from the
+        single uploaded stream; overlapped samples are not duplicated on the host."""
+        x = _as_c64(iq).reshape(-1)
+        hop = self.nfft if hop is None else int(hop)
+        if hop < 1:
+            raise ValueError("hop must be >= 1")
+        rows = 0 if x.shape[0] < self.nfft else 1 + (x.shape[0] - self.nfft) // hop
+        out = np.empty((rows, self.nfft), dtype=np.float32)
+        if rows:
+            self._run_host(lib().sdrk_exec_host, x, rows, hop, out)
+        return out
+
+    # -- device pointers (bench / pipelines that keep data resident) -------------
+    def exec_device(self, d_iq: int, n_frames: int, d_out: int, *, frame_stride: Optional[int] = None,
+                    stream: int = 0) -> None:
+        stride = self.nfft if frame_stride is None else int(frame_stride)
+        with self._lock:
+            check(lib().sdrk_exec_device(self.handle, c_void_p(d_iq), c_size_t(n_frames), c_size_t(stride),
+                                         c_void_p(d_out), c_void_p(stream) if stream else None))
+
+    def exec_device_timed(self, d_iq: int, n_frames: int, d_out: int, launches: int = 1, *,
+                          frame_stride: Optional[int] = None) -> float:
+        """Run `launches` back-to-back transforms on the plan's stream; milliseconds
+        between HIP events recorded on that stream (all launches together)."""
+        stride = self.nfft if frame_stride is None else int(frame_stride)
+        ms = c_float(0.0)
+        with self._lock:
+            check(lib().sdrk_exec_device_timed(self.handle, c_void_p(d_iq), c_size_t(n_frames),
+                                               c_size_t(stride), c_void_p(d_out), int(launches), byref(ms)))
+        return float(ms.value)
+
+    def sync(self) -> None:
+        check(lib().sdrk_plan_sync(self.handle))
+
+
+# ---- plan cache for the function API -------------------------------------------
+_plans: dict = {}
+_plans_lock = threading.Lock()
+
+
+def _cached_plan(nfft: int, window: WindowArg, eps: float, shift: bool, device: int) -> SpectrumPlan:
+    _, _, wkey = _window_spec(window, nfft)
+    key = (int(device), int(nfft), wkey, float(eps), bool(shift))
+    with _plans_lock:
+        plan = _plans.get(key)
+        if plan is None:
+            plan = SpectrumPlan(nfft, window=window, eps=eps, shift=shift, device=device)
+            _plans[key] = plan
+        return plan
+
+
+def clear_plan_cache() -> None:
+    with _plans_lock:
+        for p in _plans.values():
+            p.close()
+        _plans.clear()
+
+
+def _nfft_of(samples) -> int:
+    shape = np.shape(samples)
+    if len(shape) not in (1, 2):
+        raise ValueError(f"expected a frame (N,) or a batch (B, N), got shape {shape}")
+    return int(shape[-1])
+
+
+def spectrum_db(samples, *, window: WindowArg = None, eps: float = 1e-12, shift: bool = True,
+                device: int = 0, devices: Optional[Sequence[int]] = None) -> np.ndarray:
+    """Power spectrum in dB of one frame ``(N,)`` or a batch ``(B, N)`` of complex IQ.
+
+    Equivalent to ``20*np.log10(np.abs(np.fft.fftshift(np.fft.fft(samples*window, axis=-1),
+    axes=-1)) + eps)`` in float32 — with the defaults, exactly the reference's
+    ``power_db`` (app/sdr/streamer.py:119,121).  ``devices=[0,1,...]`` splits a
+    batch into contiguous frame ranges, one per GPU (no collectives; see
+    sharding.py).
+    """
+    nfft = _nfft_of(samples)
+    if devices is not None and len(devices) > 1 and np.ndim(samples) == 2:
+        from .sharding import spectrum_db_sharded
+        return spectrum_db_sharded(samples, devices, window=window, eps=eps, shift=shift)
+    if devices is not None and len(devices) == 1:
+        device = devices[0]
+    return _cached_plan(nfft, window, eps, shift, device).spectrum_db(samples)
+
+
+def fft_c64(samples, *, window: WindowArg = None, shift: bool = False, device: int = 0) -> np.ndarray:
+    """complex64 ``np.fft.fft(samples*window, axis=-1)`` (streamer.py:119 without the
+    log), optionally fftshifted."""
+    nfft = _nfft_of(samples)
+    return _cached_plan(nfft, window, 1e-12, shift, device).fft(samples)
+
+
+def freq_axis(n: int, sample_rate: float, center_freq: float = 0.0) -> np.ndarray:
+    """float64 frequency axis in Hz, bit-identical to the reference's
+    ``np.fft.fftshift(np.fft.fftfreq(n, 1/sample_rate)) + center_freq``
+    (app/sdr/streamer.py:120): the same float operations in the same order —
+    ``val = 1/(n*d)`` with ``d = 1/sample_rate``, integer bin index times ``val``,
+    plus ``center_freq`` — on the already-shifted index range.  Host-side; it is
+    O(n) float64 arithmetic with no kernel."""
+    n = int(n)
+    if n < 1:
+        raise ValueError("n must be >= 1")
+    d = 1 / sample_rate
+    val = 1.0 / (n * d)
+    k = np.arange(-(n // 2), (n - 1) // 2 + 1, dtype=int)
+    return k * val + center_freq
+
+
+def process_frame(samples, sample_rate: float, center_freq: float, *, window: WindowArg = None,
+                  eps: float = 1e-12, device: int = 0) -> dict:
+    """One reader-loop iteration of the reference (app/sdr/streamer.py:119-130):
+    returns the ``plot_data`` dict with exactly its keys — ``time``, ``samples``
+    (the caller's array, same object), ``freqs``, ``power_db``, ``sample_rate``,
+    ``center_freq`` — which is what ``update_graphs`` reads
+    (app/dashboard/callbacks.py:110-115)."""
+    power_db = spectrum_db(samples, window=window, eps=eps, shift=True, device=device)
+    freqs = freq_axis(len(samples), sample_rate, center_freq)
+    return {
+        "time": time.time(),
+        "samples": samples,
+        "freqs": freqs,
+        "power_db": power_db,
+        "sample_rate": sample_rate,
+        "center_freq": center_freq,
+    }
+
+
+def stft_db(iq, nfft: int, hop: Optional[int] = None, window: WindowArg = None, *, eps: float = 1e-12,
+            shift: bool = True, device: int = 0) -> np.ndarray:
+    """Spectrogram rows ``(rows, nfft)`` float32 over one contiguous IQ stream (the
+    waterfall of BASELINE.json config 3: nfft=65536, hop=nfft//2)."""
+    return _cached_plan(int(nfft), window, eps, shift, device).stft_db(iq, hop)

@@ -1,0 +1,130 @@
+"""Device-resident waterfall: the last ``maxlen`` spectrum rows, oldest first.
+
+Host-side mirror of the reference's waterfall accumulation in its dashboard
+callback:
+
+    app/dashboard/callbacks.py:19   waterfall_data = deque(maxlen=100)
+    app/dashboard/callbacks.py:176  waterfall_data.append(power_db)
+    app/dashboard/callbacks.py:182  waterfall_array = np.array(waterfall_data)
+    app/dashboard/callbacks.py:186  y=list(range(len(waterfall_data)))
+
+``WaterfallBuffer`` keeps the rows in a ring in HBM (``sdrk_waterfall_*`` in
+include/sdrk.h).  ``append`` takes either a finished ``power_db`` row (what the
+callback has today) or raw IQ frames, which are transformed on the GPU straight
+into the ring slots; ``as_array`` returns the ``(rows, nfft)`` float32 array the
+heatmap is drawn from.  The reference mutates its module-global deque from Flask
+request threads without a lock; this class takes one.
+"""
+from __future__ import annotations
+
+import threading
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import byref, c_size_t, c_void_p, check, lib
+from .spectrum import SpectrumPlan, WindowArg
+
+
+class WaterfallBuffer:
+    def __init__(self, nfft: int, maxlen: int = 100, *, device: int = 0, window: WindowArg = None,
+                 eps: float = 1e-12):
+        nfft, maxlen = int(nfft), int(maxlen)
+        if nfft < 1:
+            raise ValueError("nfft must be >= 1")
+        if maxlen < 1:
+            raise ValueError("maxlen must be >= 1")
+        _ffi.require_device(device)
+        self.nfft, self.maxlen, self.device = nfft, maxlen, int(device)
+        self._window, self._eps = window, float(eps)
+        self._plan: Optional[SpectrumPlan] = None
+        self._lock = threading.Lock()
+        self._handle = c_void_p()
+        check(lib().sdrk_waterfall_create(self.device, nfft, maxlen, byref(self._handle)))
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self) -> None:
+        h, self._handle = self._handle, c_void_p()
+        if h:
+            lib().sdrk_waterfall_destroy(h)
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _h(self) -> c_void_p:
+        if not self._handle:
+            raise RuntimeError("waterfall is closed")
+        return self._handle
+
+    # -- deque-like interface ------------------------------------------------------
+    def __len__(self) -> int:
+        return check(lib().sdrk_waterfall_rows(self._h()))
+
+    def clear(self) -> None:
+        with self._lock:
+            check(lib().sdrk_waterfall_clear(self._h()))
+
+    def append(self, row_or_frame) -> None:
+        """Append one row (real, shape ``(nfft,)``), several rows ``(r, nfft)``, or —
+        if the array is complex — one or several IQ frames to transform first."""
+        a = np.asarray(row_or_frame)
+        if np.iscomplexobj(a):
+            self.append_iq(a)
+        else:
+            self.append_rows(a)
+
+    def append_rows(self, rows) -> None:
+        r = np.ascontiguousarray(np.asarray(rows, dtype=np.float32))
+        if r.ndim == 1:
+            r = r.reshape(1, -1)
+        if r.ndim != 2 or r.shape[1] != self.nfft:
+            raise ValueError(f"expected rows of {self.nfft} values, got shape {r.shape}")
+        with self._lock:
+            check(lib().sdrk_waterfall_append_rows(self._h(), r.ctypes.data_as(c_void_p), c_size_t(r.shape[0])))
+
+    def append_iq(self, frames, hop: Optional[int] = None) -> None:
+        """Transform IQ and append the rows.  ``frames`` is ``(nfft,)``, ``(B, nfft)``,
+        or — with ``hop`` — one contiguous stream cut into overlapping frames."""
+        x = np.asarray(frames)
+        if x.dtype != np.complex64:
+            x = x.astype(np.complex64)
+        x = np.ascontiguousarray(x)
+        if hop is None:
+            if x.ndim == 1:
+                x = x.reshape(1, -1)
+            if x.ndim != 2 or x.shape[1] != self.nfft:
+                raise ValueError(f"expected frames of {self.nfft} samples, got shape {x.shape}")
+            n_frames, stride = x.shape[0], self.nfft
+        else:
+            x = x.reshape(-1)
+            stride = int(hop)
+            if stride < 1:
+                raise ValueError("hop must be >= 1")
+            n_frames = 0 if x.shape[0] < self.nfft else 1 + (x.shape[0] - self.nfft) // stride
+        if n_frames == 0:
+            return
+        with self._lock:
+            if self._plan is None:
+                self._plan = SpectrumPlan(self.nfft, window=self._window, eps=self._eps, shift=True,
+                                          device=self.device)
+            check(lib().sdrk_waterfall_append_iq(self._h(), self._plan.handle, x.ctypes.data_as(c_void_p),
+                                                 c_size_t(n_frames), c_size_t(stride)))
+
+    def as_array(self, max_rows: Optional[int] = None) -> np.ndarray:
+        """``np.array(deque)``: float32 ``(rows, nfft)``, oldest row at index 0.  With
+        ``max_rows`` only the newest ``max_rows`` rows are returned."""
+        with self._lock:
+            rows = len(self)
+            if max_rows is not None:
+                rows = min(rows, int(max_rows))
+            out = np.empty((rows, self.nfft), dtype=np.float32)
+            got = c_size_t(0)
+            check(lib().sdrk_waterfall_read(self._h(), out.ctypes.data_as(c_void_p), c_size_t(rows), byref(got)))
+            return out[: got.value]

@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sdrk.h declares;
+the ctypes table in _ffi.py covers the same set.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests.conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "sdrk.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdrk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_symbols()
+    for must in ("sdrk_plan_create", "sdrk_exec_host", "sdrk_exec_device", "sdrk_waterfall_create",
+                 "sdrk_waterfall_append_rows", "sdrk_waterfall_read", "sdrk_synth_fill",
+                 "sdrk_last_error", "sdrk_version", "sdrk_device_count", "sdrk_plan_destroy"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from sdr_iq_visualizer_amd import _ffi
+    assert os.path.exists(_ffi.library_path()), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    handle = ctypes.CDLL(_ffi.library_path())
+    for name in declared_symbols():
+        assert hasattr(handle, name), f"{name} declared in sdrk.h but not exported"
+
+
+def test_ctypes_table_matches_header():
+    from sdr_iq_visualizer_amd import _ffi
+    table = sorted(name for name, _, _ in _ffi.SYMBOLS)
+    assert table == declared_symbols()
+
+
+def test_version_and_error_string_without_gpu():
+    from sdr_iq_visualizer_amd import _ffi
+    lib = _ffi.lib()
+    assert lib.sdrk_version() == 100
+    assert isinstance(lib.sdrk_last_error(), bytes)
+    assert lib.sdrk_device_count() >= 0
+
+
+def test_product_path_fails_loudly_without_a_device():
+    """No CPU fallback: with no GPU the numpy-facing API raises, it does not compute."""
+    import numpy as np
+    import sdr_iq_visualizer_amd as pkg
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.SdrkError):
+        pkg.spectrum_db(np.zeros(4096, dtype=np.complex64))
+    with pytest.raises(pkg.SdrkError):
+        pkg.WaterfallBuffer(4096)
+    with pytest.raises(pkg.SdrkError):
+        pkg.process_frame(np.zeros(4096, dtype=np.complex64), 1e6, 2.4e9)

@@ -1,0 +1,83 @@
+"""CPU: host-side logic of the package that needs no GPU — frequency axis,
+sharding arithmetic, window/argument validation, the numpy mirror of the device
+generator."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from sdr_iq_visualizer_amd import sharding, spectrum, synth
+
+
+@pytest.mark.parametrize("n,fs,fc", [
+    (4096, 1_000_000, 2_400_000_000),       # reference defaults, streamer.py:8-10
+    (4096, 1e6, 2.4e9), (65536, 61_440_000, 915_000_000), (1 << 20, 61.44e6, 0.0),
+    (2, 1.0, 0.0), (7, 48_000, 100.5), (1001, 2_048_000, 433_920_000), (1, 10.0, 5.0),
+])
+def test_freq_axis_bit_identical_to_reference_expression(n, fs, fc):
+    got = spectrum.freq_axis(n, fs, fc)
+    ref = cpu_ref.freq_axis(n, fs, fc)   # np.fft.fftshift(np.fft.fftfreq(n, 1/fs)) + fc
+    assert got.dtype == np.float64 and got.shape == (n,)
+    assert np.array_equal(got, ref)
+
+
+def test_freq_axis_rejects_bad_n():
+    with pytest.raises(ValueError):
+        spectrum.freq_axis(0, 1e6, 0.0)
+
+
+def test_shard_ranges_cover_and_balance():
+    for n in (0, 1, 5, 8, 1000, (1 << 23)):
+        for s in (1, 2, 3, 4, 8):
+            r = sharding.shard_ranges(n, s)
+            assert len(r) == s and r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert sharding.shard_ranges(1 << 23, 8)[3] == (3 << 20, 4 << 20)   # BASELINE config 4
+    assert sharding.rank_range(10, 1, 4) == (3, 6)
+    with pytest.raises(ValueError):
+        sharding.shard_ranges(4, 0)
+
+
+def test_window_spec():
+    k, w, key = spectrum._window_spec(None, 8)
+    assert (k, w, key) == (0, None, "rect")
+    assert spectrum._window_spec("hann", 8)[0] == 1 and spectrum._window_spec("Hanning", 8)[2] == "hann"
+    k, w, key = spectrum._window_spec(np.hanning(8), 8)
+    assert k == 2 and w.dtype == np.float32 and w.flags.c_contiguous
+    with pytest.raises(ValueError):
+        spectrum._window_spec(np.ones(7), 8)
+    with pytest.raises(ValueError):
+        spectrum._window_spec("kaiser", 8)
+
+
+def test_plan_rejects_bad_nfft_before_touching_the_device():
+    for bad in (0, 1, 3, 4095, 1 << 23):
+        with pytest.raises(ValueError):
+            spectrum.SpectrumPlan(bad)
+
+
+def test_synth_known_values_and_shape():
+    x = synth.synth_iq(1234, 0, 2, 4096)
+    assert x.dtype == np.complex64 and x.shape == (2, 4096)
+    assert np.all(x.real == np.round(x.real)) and np.all(x.imag == np.round(x.imag))
+    assert x.real.min() >= -2048 and x.real.max() <= 2047
+    # fmix32 test vectors (MurmurHash3 finaliser)
+    assert int(synth.fmix32(np.uint64(0))) == 0
+    assert int(synth.fmix32(np.uint64(1))) == 0x514E28B7
+    assert int(synth.fmix32(np.uint64(0xFFFFFFFF))) == 0x81F16F39
+    # frame numbering is 64-bit: frames beyond 2^32 differ from their low-word aliases
+    a = synth.synth_iq(1, (1 << 32) + 5, 1, 64)
+    b = synth.synth_iq(1, 5, 1, 64)
+    assert not np.array_equal(a, b)
+    # a slice of a batch equals the same frames generated alone
+    assert np.array_equal(synth.synth_iq(9, 100, 4, 256)[2:], synth.synth_iq(9, 102, 2, 256))
+    # roughly zero-mean, full 12-bit spread
+    big = synth.synth_iq(7, 0, 16, 4096)
+    assert abs(big.real.mean()) < 10 and 1100 < big.real.std() < 1250
+
+
+def test_tone_is_on_bin():
+    t = synth.tone(64, 5.0)
+    X = np.fft.fft(t.astype(np.complex128))
+    assert int(np.argmax(np.abs(X))) == 5 and abs(abs(X[5]) - 64) < 1e-3

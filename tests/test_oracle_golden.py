@@ -1,0 +1,104 @@
+"""CPU: pin the oracle (oracle/cpu_ref.py) against outputs of the reference itself.
+
+The fixtures in tests/golden/ were produced by oracle/make_golden.py, which ran the
+reference's own reader loop (app/sdr/streamer.py:95-133) on fixed inputs.  The
+oracle is the same numpy expression, so on the same numpy build it reproduces the
+float32 rows bit for bit; across hosts with a different numpy SIMD dispatch the
+rows may differ in the last ulp of the transform, hence the 2e-6 peak-relative bound
+(5x tighter than the GPU parity bar) rather than array_equal.
+"""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from tests.parity import assert_db_parity, peak_rel_err
+
+
+def test_oracle_matches_reference_n4096(golden):
+    g = golden["ref_n4096"]
+    names = [str(n) for n in g["names"]]
+    assert len(names) == 10
+    for name in names:
+        iq = g[f"{name}/iq"]
+        assert iq.dtype == np.complex64 and iq.shape == (4096,)
+        ref32 = g[f"{name}/power_db_c64"]
+        got32 = cpu_ref.spectrum_db(iq)
+        assert got32.dtype == np.float32
+        assert peak_rel_err(got32, ref32) <= 2e-6, name
+        ref64 = g[f"{name}/power_db_c128"]
+        got64 = cpu_ref.spectrum_db(iq.astype(np.complex128))
+        assert got64.dtype == np.float64
+        assert peak_rel_err(got64, ref64) <= 1e-12, name
+
+
+def test_reference_exact_values(golden):
+    """Closed-form rows the reference itself produced: zeros -> one constant,
+    20*log10(float32(1e-12)) = -240.00002 in numpy's float32, unit impulse -> 0 dB
+    (+ 1e-12 floor) everywhere,
+    on-bin tone -> peak 20*log10(4096) at shifted index 2048+100."""
+    g = golden["ref_n4096"]
+    z = g["zeros/power_db_c64"]
+    assert np.all(z == z[0]) and abs(float(z[0]) + 240.0) < 1e-4
+    assert np.allclose(g["impulse_n0/power_db_c64"], 0.0, atol=1e-6)
+    assert np.allclose(g["impulse_n1/power_db_c64"], 0.0, atol=1e-5)
+    tone = g["tone_onbin_k100/power_db_c64"]
+    assert int(np.argmax(tone)) == 2048 + 100
+    assert abs(float(tone.max()) - 20 * np.log10(4096.0)) < 1e-4
+    dc = g["dc/power_db_c64"]
+    assert int(np.argmax(dc)) == 2048
+
+
+def test_oracle_matches_reference_other_sizes(golden):
+    g = golden["ref_other_sizes"]
+    for n in (2, 8, 64, 256, 1024, 2048, 8192):
+        iq = g[f"n{n}/iq"]
+        assert iq.shape == (n,)
+        assert peak_rel_err(cpu_ref.spectrum_db(iq), g[f"n{n}/power_db_c64"]) <= 2e-6
+        assert np.array_equal(cpu_ref.freq_axis(n, 2_000_000, 915_000_000), g[f"n{n}/freqs"])
+
+
+def test_freq_axis_default_values(golden):
+    """2 399 500 000 ... 2 400 499 755.859375 at the reference defaults."""
+    f = golden["ref_n4096"]["freqs_default"]
+    assert f.dtype == np.float64 and f.shape == (4096,)
+    assert f[0] == 2_399_500_000.0 and f[2048] == 2_400_000_000.0 and f[-1] == 2_400_499_755.859375
+    assert np.array_equal(cpu_ref.freq_axis(4096, 1_000_000, 2_400_000_000), f)
+
+
+@pytest.mark.parametrize("n", [65536, 1 << 20])
+def test_oracle_matches_reference_large_sampled(golden, n):
+    from sdr_iq_visualizer_amd import synth
+    g = golden["ref_large_sampled"]
+    seed, first = (int(v) for v in g[f"n{n}/seed"])
+    kbin, amp = (float(v) for v in g[f"n{n}/tone_bin_amp"])
+    x = (synth.synth_iq(seed, first, 1, n)[0] + synth.tone(n, kbin, amplitude=amp)).astype(np.complex64)
+    p = cpu_ref.spectrum_db(x)
+    idx = g[f"n{n}/idx"]
+    ref = g[f"n{n}/power_db_c64_at_idx"]
+    scale = 10 ** (float(p.max()) / 20)
+    err = np.abs(10 ** (p[idx].astype(np.float64) / 20) - 10 ** (ref.astype(np.float64) / 20)).max() / scale
+    assert err <= 2e-6
+    assert int(np.argmax(p)) == int(g[f"n{n}/argmax"][0])
+    assert abs(float(np.sum(p.astype(np.float64))) - float(g[f"n{n}/sum_db"][0])) <= 1e-6 * n
+
+
+def test_oracle_waterfall_matches_deque(golden):
+    g = golden["ref_waterfall"]
+    wf = cpu_ref.Waterfall(maxlen=100)
+    for r in g["rows_in"]:
+        wf.append(r)
+    out = wf.as_array()
+    assert out.shape == (100, 16) and len(wf) == 100
+    assert np.array_equal(out, g["array_out"])
+    assert out[0, 0] == 3.0 and out[-1, 0] == 102.0  # rows 3..102, oldest first
+
+
+def test_oracle_stft_and_window():
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(1000) + 1j * rng.standard_normal(1000)).astype(np.complex64)
+    rows = cpu_ref.stft_db(x, 256, 128, window=cpu_ref.hann(256))
+    assert rows.shape == (1 + (1000 - 256) // 128, 256) and rows.dtype == np.float32
+    assert_db_parity(rows[2], cpu_ref.spectrum_db(x[256:512], window=np.hanning(256)))
+    assert cpu_ref.stft_db(x[:100], 256, 128).shape == (0, 256)
+    w = cpu_ref.hann(4096)
+    assert w[0] == 0.0 and w[-1] == 0.0 and np.allclose(w, w[::-1])

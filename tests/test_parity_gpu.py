@@ -1,0 +1,308 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI (ctypes), against
+(1) the committed outputs of the reference itself, (2) the CPU oracle on seeded
+inputs, (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: 1e-5 relative (north_star), taken against each frame's peak magnitude —
+see tests/parity.py.  Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from tests.parity import assert_complex_parity, assert_db_parity, peak_rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import sdr_iq_visualizer_amd as p
+    assert p.device_count() >= 1, "no GPU visible: the product path has no CPU fallback"
+    assert "gfx950" in p.device_info(0)
+    return p
+
+
+def rand_c64(rng, *shape, scale=1.0):
+    return ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * scale).astype(np.complex64)
+
+
+# ---- (1) the reference's own outputs ------------------------------------------------
+
+def test_golden_n4096_against_reference_outputs(pkg, golden):
+    g = golden["ref_n4096"]
+    for name in (str(n) for n in g["names"]):
+        got = pkg.spectrum_db(g[f"{name}/iq"])
+        assert got.shape == (4096,) and got.dtype == np.float32
+        assert_db_parity(got, g[f"{name}/power_db_c64"], what=f"{name} vs reference(c64)")
+        # the reference fed complex128 (what pyadi-iio delivers) computes in float64:
+        assert_db_parity(got, g[f"{name}/power_db_c128"].astype(np.float32), what=f"{name} vs reference(c128)")
+
+
+def test_golden_exact_structure(pkg, golden):
+    g = golden["ref_n4096"]
+    z = pkg.spectrum_db(g["zeros/iq"])
+    assert np.all(z == z[0]) and abs(float(z[0]) + 240.0) < 1e-4          # eps floor only
+    imp = pkg.spectrum_db(g["impulse_n0/iq"])
+    assert np.abs(imp).max() < 1e-5                                       # |X| = 1 everywhere
+    tone = pkg.spectrum_db(g["tone_onbin_k100/iq"])
+    assert int(np.argmax(tone)) == 2048 + 100                             # fftshift: DC at N/2
+    assert abs(float(tone.max()) - 20 * np.log10(4096.0)) < 1e-3
+
+
+def test_golden_other_sizes_through_generic_kernels(pkg, golden):
+    g = golden["ref_other_sizes"]
+    for n in (2, 8, 64, 256, 1024, 2048, 8192):
+        got = pkg.spectrum_db(g[f"n{n}/iq"])
+        assert_db_parity(got, g[f"n{n}/power_db_c64"], what=f"n={n}")
+
+
+@pytest.mark.parametrize("n", [65536, 1 << 20])
+def test_golden_large_frames_sampled_bins(pkg, golden, n):
+    """BASELINE.json configs 3 and 5 frame sizes, against bins the reference computed."""
+    from sdr_iq_visualizer_amd import synth
+    g = golden["ref_large_sampled"]
+    seed, first = (int(v) for v in g[f"n{n}/seed"])
+    kbin, amp = (float(v) for v in g[f"n{n}/tone_bin_amp"])
+    x = (synth.synth_iq(seed, first, 1, n)[0] + synth.tone(n, kbin, amplitude=amp)).astype(np.complex64)
+    p = pkg.spectrum_db(x)
+    assert p.shape == (n,)
+    idx, ref = g[f"n{n}/idx"], g[f"n{n}/power_db_c64_at_idx"]
+    scale = 10 ** (float(ref.max()) / 20)
+    err = np.abs(10 ** (p[idx].astype(np.float64) / 20) - 10 ** (ref.astype(np.float64) / 20)).max() / scale
+    assert err <= 1e-5, err
+    assert int(np.argmax(p)) == int(g[f"n{n}/argmax"][0])
+    assert abs(float(np.sum(p.astype(np.float64))) - float(g[f"n{n}/sum_db"][0])) <= 2e-5 * n
+    assert_db_parity(p, cpu_ref.spectrum_db(x), what=f"n={n} full row vs oracle")
+
+
+# ---- (2) seeded inputs vs the oracle --------------------------------------------------
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 17, 64, 1000, 3077])
+def test_batches_n4096_vs_oracle(pkg, batch):
+    """Ragged batch sizes around the persistent grid (768 workgroups) and the pipeline tail."""
+    rng = np.random.default_rng(batch)
+    x = rand_c64(rng, batch, 4096, scale=700.0)
+    got = pkg.spectrum_db(x)
+    assert got.shape == (batch, 4096)
+    assert_db_parity(got, cpu_ref.spectrum_db(x), what=f"batch {batch}")
+
+
+def test_empty_batch(pkg):
+    out = pkg.spectrum_db(np.empty((0, 4096), dtype=np.complex64))
+    assert out.shape == (0, 4096) and out.dtype == np.float32
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768,
+                               65536, 1 << 17, 1 << 18])
+def test_every_power_of_two_vs_oracle(pkg, n):
+    rng = np.random.default_rng(n)
+    b = 5 if n <= 65536 else 2
+    x = rand_c64(rng, b, n, scale=3.0)
+    assert_db_parity(pkg.spectrum_db(x), cpu_ref.spectrum_db(x), what=f"n={n}")
+    assert_complex_parity(pkg.fft_c64(x), cpu_ref.fft(x), what=f"fft n={n}")
+
+
+@pytest.mark.parametrize("n", [1 << 20, 1 << 22])
+def test_largest_frames_vs_oracle(pkg, n):
+    rng = np.random.default_rng(n)
+    x = rand_c64(rng, 1, n, scale=0.5)
+    assert_db_parity(pkg.spectrum_db(x), cpu_ref.spectrum_db(x), what=f"n={n}")
+
+
+@pytest.mark.parametrize("n", [64, 4096, 65536])
+def test_windows_eps_shift_options(pkg, n):
+    rng = np.random.default_rng(100 + n)
+    x = rand_c64(rng, 4, n, scale=50.0)
+    hann = np.hanning(n)
+    assert_db_parity(pkg.spectrum_db(x, window="hann"), cpu_ref.spectrum_db(x, window=hann), what="hann")
+    w = rng.uniform(0.1, 2.0, n).astype(np.float32)
+    assert_db_parity(pkg.spectrum_db(x, window=w), cpu_ref.spectrum_db(x, window=w), what="custom window")
+    assert_db_parity(pkg.spectrum_db(x, shift=False), cpu_ref.spectrum_db(x, shift=False), what="no shift")
+    # legacy floors of the reference's scripts: 1e-10 (scripts/sdr_realtime_dash.py:73) and none
+    # (scripts/pyad-iio-test.py:61)
+    assert_db_parity(pkg.spectrum_db(x, eps=1e-10), cpu_ref.spectrum_db(x, eps=1e-10), what="eps 1e-10")
+    assert_db_parity(pkg.spectrum_db(x, eps=0.0), cpu_ref.spectrum_db(x, eps=0.0), what="eps 0")
+    assert_complex_parity(pkg.fft_c64(x, window="hann", shift=True), cpu_ref.fft(x, window=hann, shift=True))
+
+
+def test_eps_matters_at_low_level(pkg):
+    """The floor is added to |X| (not |X|^2) before the log: streamer.py:121."""
+    x = np.full(4096, 1e-16 + 0j, dtype=np.complex64)          # |X[0]| = 4.096e-13 < eps
+    got = pkg.spectrum_db(x)
+    ref = cpu_ref.spectrum_db(x)
+    assert_db_parity(got, ref)
+    assert abs(float(got[2048]) - 20 * np.log10(4.096e-13 + 1e-12)) < 1e-3
+
+
+def test_input_dtypes_and_layouts(pkg):
+    rng = np.random.default_rng(3)
+    x128 = rng.standard_normal((3, 4096)) + 1j * rng.standard_normal((3, 4096))
+    ref = cpu_ref.spectrum_db(x128.astype(np.complex64))
+    assert_db_parity(pkg.spectrum_db(x128), ref, what="complex128 input is down-cast")
+    xs = np.asfortranarray(x128.astype(np.complex64))
+    assert_db_parity(pkg.spectrum_db(xs), ref, what="non-contiguous input is copied")
+    ints = (rng.integers(-2048, 2048, (2, 4096)) + 1j * rng.integers(-2048, 2048, (2, 4096)))
+    assert_db_parity(pkg.spectrum_db(ints), cpu_ref.spectrum_db(ints.astype(np.complex64)), what="integer IQ")
+    with pytest.raises(ValueError):
+        pkg.spectrum_db(np.zeros(4095, dtype=np.complex64))       # not a power of two
+    with pytest.raises(ValueError):
+        pkg.spectrum_db(np.zeros((2, 3, 8), dtype=np.complex64))
+
+
+def test_process_frame_dict_contract(pkg):
+    """Keys and types of plot_data (app/sdr/streamer.py:123-130) as update_graphs reads them
+    (app/dashboard/callbacks.py:110-115)."""
+    rng = np.random.default_rng(11)
+    samples = rand_c64(rng, 4096, scale=900.0)
+    d = pkg.process_frame(samples, 1_000_000, 2_400_000_000)
+    assert list(d) == ["time", "samples", "freqs", "power_db", "sample_rate", "center_freq"]
+    assert d["samples"] is samples and isinstance(d["time"], float)
+    assert d["sample_rate"] == 1_000_000 and d["center_freq"] == 2_400_000_000
+    assert np.array_equal(d["freqs"], cpu_ref.freq_axis(4096, 1_000_000, 2_400_000_000))
+    assert_db_parity(d["power_db"], cpu_ref.spectrum_db(samples))
+    peaks = d["power_db"][np.array([1, 5, 9])]                    # integer-array indexing (:162-163)
+    assert peaks.shape == (3,) and np.isfinite(np.median(d["power_db"]))
+
+
+def test_stft_overlap_vs_oracle(pkg):
+    rng = np.random.default_rng(21)
+    x = rand_c64(rng, 50_000, scale=10.0)
+    for nfft, hop in ((4096, 2048), (4096, 4096), (4096, 1000), (1024, 256), (8192, 4096)):
+        got = pkg.stft_db(x, nfft, hop, window="hann")
+        ref = cpu_ref.stft_db(x, nfft, hop, window=np.hanning(nfft))
+        assert got.shape == ref.shape == (1 + (50_000 - nfft) // hop, nfft)
+        assert_db_parity(got, ref, what=f"stft {nfft}/{hop}")
+    assert pkg.stft_db(x[:100], 4096, 2048).shape == (0, 4096)
+
+
+def test_stft_n65536_half_overlap(pkg):
+    """Shape of BASELINE.json config 3 (N=65536, 50 % overlap) on a short stream."""
+    from sdr_iq_visualizer_amd import synth
+    n, hop, rows = 65536, 32768, 6
+    L = n + (rows - 1) * hop
+    x = (synth.synth_iq(5, 0, 1, L if L % 2 == 0 else L + 1)[0][:L]
+         + synth.tone(L, L / 7.0, amplitude=100.0)).astype(np.complex64)
+    got = pkg.stft_db(x, n, hop, window="hann")
+    ref = cpu_ref.stft_db(x, n, hop, window=np.hanning(n))
+    assert got.shape == (rows, n)
+    assert_db_parity(got, ref, what="stft 65536/32768")
+
+
+# ---- waterfall ring --------------------------------------------------------------------
+
+def test_waterfall_matches_deque_semantics(pkg, golden):
+    g = golden["ref_waterfall"]
+    wf = pkg.WaterfallBuffer(16, maxlen=100)
+    assert len(wf) == 0 and wf.as_array().shape == (0, 16)
+    for i, r in enumerate(g["rows_in"]):
+        wf.append(r)
+        assert len(wf) == min(i + 1, 100)
+    assert np.array_equal(wf.as_array(), g["array_out"])         # rows 3..102, oldest first
+    assert np.array_equal(wf.as_array(max_rows=7), g["array_out"][-7:])
+    wf.clear()
+    assert len(wf) == 0
+    wf.append(g["rows_in"][:5])                                   # several rows at once
+    assert np.array_equal(wf.as_array(), g["rows_in"][:5])
+    wf.append(g["rows_in"])                                       # 103 rows into maxlen 100
+    assert np.array_equal(wf.as_array(), g["array_out"])
+    wf.close()
+
+
+def test_waterfall_append_iq_on_device(pkg):
+    rng = np.random.default_rng(8)
+    frames = rand_c64(rng, 23, 4096, scale=100.0)
+    ref_rows = cpu_ref.spectrum_db(frames)
+    oracle = cpu_ref.Waterfall(maxlen=10)
+    wf = pkg.WaterfallBuffer(4096, maxlen=10)
+    for lo, hi in ((0, 1), (1, 4), (4, 9), (9, 12), (12, 23)):    # crosses the ring wrap twice
+        wf.append(frames[lo:hi])
+        for r in ref_rows[lo:hi]:
+            oracle.append(r)
+        got, ref = wf.as_array(), oracle.as_array()
+        assert got.shape == ref.shape
+        assert_db_parity(got, ref, what=f"ring after {hi} frames")
+    wf2 = pkg.WaterfallBuffer(4096, maxlen=100, window="hann")
+    stream = rand_c64(rng, 4096 * 6, scale=5.0)
+    wf2.append_iq(stream, hop=2048)
+    assert_db_parity(wf2.as_array(), cpu_ref.stft_db(stream, 4096, 2048, window=np.hanning(4096)))
+    with pytest.raises(ValueError):
+        wf.append(np.zeros(100, dtype=np.float32))
+
+
+# ---- device generator -----------------------------------------------------------------
+
+def test_device_generator_bit_identical_to_numpy_mirror(pkg):
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, synth
+    lib = _ffi.lib()
+    for seed, first, nf, n in ((1234, 0, 3, 4096), (7, (1 << 32) + 5, 2, 64), (1, 10, 1, 65536)):
+        d = ctypes.c_void_p()
+        _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 8, ctypes.byref(d)))
+        try:
+            _ffi.check(lib.sdrk_synth_fill(0, seed, first, nf, n, d, None))
+            host = np.empty((nf, n), dtype=np.complex64)
+            _ffi.check(lib.sdrk_memcpy_d2h(0, host.ctypes.data_as(ctypes.c_void_p), d, host.nbytes))
+        finally:
+            _ffi.check(lib.sdrk_dev_free(0, d))
+        assert np.array_equal(host.view(np.uint32), synth.synth_iq(seed, first, nf, n).view(np.uint32))
+
+
+# ---- (3) full-size properties (BASELINE.json configs 2 and 4 shapes) -------------------
+
+def test_full_size_device_resident_run_properties(pkg):
+    """2^16 frames x 4096 generated on the device (a 1/16 slice of config 2's 2^20 so the test
+    stays quick; bench.py runs the full 2^20): sampled frames agree with the oracle on the
+    numpy-regenerated input, and every row's power sum satisfies Parseval against its input."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, synth
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    nf, n, seed, first = 1 << 16, 4096, 1234, 1 << 20
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 8, ctypes.byref(d_in)))
+    _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 4, ctypes.byref(d_out)))
+    try:
+        _ffi.check(lib.sdrk_synth_fill(0, seed, first, nf, n, d_in, None))
+        with SpectrumPlan(n, window="hann") as plan:
+            plan.exec_device(d_in.value, nf, d_out.value)
+            plan.sync()
+            rng = np.random.default_rng(0)
+            picks = np.unique(np.concatenate([[0, 1, 767, 768, 769, nf - 1], rng.integers(0, nf, 58)]))
+            row = np.empty(n, dtype=np.float32)
+            w = np.hanning(n)
+            for f in picks:
+                _ffi.check(lib.sdrk_memcpy_d2h(0, row.ctypes.data_as(ctypes.c_void_p),
+                                               ctypes.c_void_p(d_out.value + int(f) * n * 4), row.nbytes))
+                x = synth.synth_iq(seed, first + int(f), 1, n)[0]
+                assert_db_parity(row, cpu_ref.spectrum_db(x, window=w), what=f"frame {f}")
+                # Parseval: sum |X|^2 = N * sum |w x|^2
+                p_out = np.sum(np.power(10.0, row.astype(np.float64) / 10.0))
+                p_in = n * np.sum(np.abs(x.astype(np.complex128) * w) ** 2)
+                assert abs(p_out / p_in - 1.0) < 1e-4
+    finally:
+        lib.sdrk_dev_free(0, d_in)
+        lib.sdrk_dev_free(0, d_out)
+
+
+def test_linearity_and_shift_theorem(pkg):
+    """Size-independent properties of the transform itself (complex output)."""
+    rng = np.random.default_rng(2)
+    for n in (4096, 65536):
+        a, b = rand_c64(rng, 2, n), rand_c64(rng, 2, n)
+        Fa, Fb, Fab = pkg.fft_c64(a), pkg.fft_c64(b), pkg.fft_c64((2 * a - 3 * b).astype(np.complex64))
+        assert_complex_parity(Fab, 2 * Fa.astype(np.complex128) - 3 * Fb.astype(np.complex128), rel=2e-5)
+        # circular shift by one sample multiplies bin k by exp(-2 pi i k / n)
+        Fr = pkg.fft_c64(np.roll(a, 1, axis=-1))
+        k = np.arange(n)
+        assert_complex_parity(Fr, Fa.astype(np.complex128) * np.exp(-2j * np.pi * k / n), rel=2e-5)
+
+
+def test_thread_per_device_sharding_single_gpu(pkg):
+    """sharding.spectrum_db_sharded with the same device listed twice: two threads, two
+    frame ranges, one gathered array (multi-GPU boxes run it with distinct devices)."""
+    from sdr_iq_visualizer_amd import sharding
+    rng = np.random.default_rng(4)
+    x = rand_c64(rng, 37, 4096, scale=20.0)
+    out = sharding.spectrum_db_sharded(x, [0, 0])
+    assert_db_parity(out, cpu_ref.spectrum_db(x))
+    assert np.array_equal(out, pkg.spectrum_db(x, devices=[0]))
