@@ -29,6 +29,16 @@
 // transformed, so each resident workgroup keeps 32 KiB of HBM reads outstanding.
 #include "fft4096_core.h"
 
+#ifndef F4K_FASTLOG
+#define F4K_FASTLOG 0  // 1: skip the sqrt when |X| >= eps*2^25 on every lane of the wave
+#endif
+#ifndef F4K_WINREG
+#define F4K_WINREG 0   // 1: window coefficients in 16 VGPRs per thread instead of a 16 KiB LDS copy
+#endif
+#ifndef F4K_NT
+#define F4K_NT 2       // cache-policy bits of the streaming loads/stores (2 = nt)
+#endif
+
 namespace sdrk {
 
 template <bool HAS_WINDOW, int EPILOGUE>
@@ -36,21 +46,32 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     const float2* __restrict__ iq, size_t frame_stride, void* __restrict__ out_raw,
     size_t n_frames, const float* __restrict__ window, const float2* __restrict__ tw4096,
     float eps, int shift) {
-    __shared__ float2 lds[F4K_XCH_ELEMS + F4K_TW_ELEMS + (HAS_WINDOW ? F4K_N / 2 : 0)];
+    __shared__ float2 lds[F4K_XCH_ELEMS + F4K_TW_ELEMS + ((HAS_WINDOW && !F4K_WINREG) ? F4K_N / 2 : 0)];
     float2* __restrict__ tw256 = lds + F4K_XCH_ELEMS;  // [k][n] = W256^(n k)
     float2* __restrict__ tw4k = tw256 + 256;           // [k][n] = W4096^(n k), n,k < 16
     float* __restrict__ lds_win = reinterpret_cast<float*>(tw4k + 256);
 
     const int tid = threadIdx.x;
-    const F4kAddr A = f4k_addr(tid);
-    f4k_init_tables(tw256, tw4k, tw4096, tid);
+    F4kAddr A = f4k_addr(tid);
+    f4k_init_tables(tw256, tw4k, tw4096, tid, A);
+#if F4K_WINREG
+    float win[16];
+    if (HAS_WINDOW) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) win[j] = window[tid + 256 * j];
+    }
+#else
     if (HAS_WINDOW) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) lds_win[tid + 256 * j] = window[tid + 256 * j];
     }
+#endif
     __syncthreads();
 
     const int xor_k2 = shift ? 8 : 0;
+#if F4K_FASTLOG
+    const float fast_thresh = (eps * 33554432.0f) * (eps * 33554432.0f);  // (eps * 2^25)^2
+#endif
     const int voff_in = tid * 8;
     constexpr int OUT_ELEM = (EPILOGUE == EPI_LOGPSD ? 4 : 8);
     const int voff_out = tid * OUT_ELEM;
@@ -64,7 +85,7 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
         __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + first * frame_stride, F4K_N * 8);
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, 2 /*nt*/);
+            nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, F4K_NT);
     }
     for (size_t f = first; f < n_frames; f += step) {
         cf v[16];
@@ -79,23 +100,47 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
             __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + fn * frame_stride, F4K_N * 8);
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, 2 /*nt*/);
+                nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, F4K_NT);
         }
         if (HAS_WINDOW) {
 #pragma unroll
+#if F4K_WINREG
+            for (int j = 0; j < 16; ++j) v[j] = v[j] * win[j];
+#else
             for (int j = 0; j < 16; ++j) v[j] = v[j] * lds_win[tid + 256 * j];
+#endif
         }
         f4k_transform(v, lds, tw256, tw4k, A, tid);
         // ---- epilogue + store: bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor) ----
         __amdgpu_buffer_rsrc_t w = frame_rsrc(
             static_cast<char*>(out_raw) + f * (size_t)(F4K_N * OUT_ELEM), F4K_N * OUT_ELEM);
         if (EPILOGUE == EPI_LOGPSD) {
+#if F4K_FASTLOG
+            float p[16], pmin;
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 cf z = v[rev16(k2)];
-                float db = logpsd_db(z.x, z.y, eps);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, db), w, voff_out,
-                                                      (k2 ^ xor_k2) * 1024, 2 /*nt*/);
+                p[k2] = fmaf(z.x, z.x, z.y * z.y);
+            }
+            pmin = fminf(fminf(fminf(p[0], p[1]), fminf(p[2], p[3])), fminf(fminf(p[4], p[5]), fminf(p[6], p[7])));
+            pmin = fminf(pmin, fminf(fminf(fminf(p[8], p[9]), fminf(p[10], p[11])),
+                                     fminf(fminf(p[12], p[13]), fminf(p[14], p[15]))));
+            // NaN compares false -> slow path, which propagates it like the reference does.
+            if (__builtin_amdgcn_ballot_w64(!(pmin >= fast_thresh)) == 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, logpsd_db_fast(p[k2])), w,
+                                                          voff_out, (k2 ^ xor_k2) * 1024, F4K_NT);
+            } else
+#endif
+            {
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    cf z = v[rev16(k2)];
+                    float db = logpsd_db(z.x, z.y, eps);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, db), w, voff_out,
+                                                          (k2 ^ xor_k2) * 1024, F4K_NT);
+                }
             }
         } else {
 #pragma unroll

@@ -28,6 +28,7 @@ struct F4kAddr {
     int x1w_even, x1w_odd;  // exchange-1 write: (tid ^ 16*(k&1)) + 256 k
     int x1r_even, x1r_odd;  // exchange-1 read : lo + 16 (j ^ (hi&1)) + 256 hi
     int x2w;                // exchange-2 write: hi + 16 k + 257 lo ; read: tid + 257 j
+    cf w1_4096, w1_256;     // F4K_TWCHAIN: W4096^tid and W256^lo
 };
 
 __device__ __forceinline__ F4kAddr f4k_addr(int tid) {
@@ -46,10 +47,42 @@ __device__ __forceinline__ F4kAddr f4k_addr(int tid) {
 // Fill the two 2 KiB twiddle tables [k][n] from the global W4096^m table.
 // Caller must __syncthreads() before the first f4k_transform().
 __device__ __forceinline__ void f4k_init_tables(float2* __restrict__ tw256, float2* __restrict__ tw4k,
-                                                const float2* __restrict__ tw4096, int tid) {
+                                                const float2* __restrict__ tw4096, int tid, F4kAddr& A) {
+    {
+        float2 a = tw4096[tid], b = tw4096[16 * (tid & 15)];
+        A.w1_4096 = cf{a.x, a.y};
+        A.w1_256 = cf{b.x, b.y};
+    }
     const int lo = tid & 15, hi = tid >> 4;
     tw256[tid] = tw4096[(16 * lo * hi) & (F4K_N - 1)];  // [k=hi][n=lo] = W256^(lo hi)
     tw4k[tid] = tw4096[lo * hi];                         // [k=hi][n=lo] = W4096^(lo hi)
+}
+
+// Tuning switches (tools/kbench.hip builds variants; production uses the defaults).
+#ifndef F4K_TWCHAIN
+#define F4K_TWCHAIN 0   // 1: inter-pass twiddles w^k by a depth<=4 product tree from w^1 (no LDS tables)
+#endif
+#ifndef F4K_ABLATE
+#define F4K_ABLATE 0    // timing-only ablations (wrong results): 1 = no LDS exchange / barriers
+#endif
+
+// w[k] = w1^k for k = 1..15 with multiplication depth <= 4 (w2=w1^2, w4=w2^2, w8=w4^2).
+__device__ __forceinline__ void pow_tree(cf w1, cf (&w)[16]) {
+    w[1] = w1;
+    w[2] = cmul(w1, w1);
+    w[3] = cmul(w[2], w1);
+    w[4] = cmul(w[2], w[2]);
+    w[5] = cmul(w[4], w1);
+    w[6] = cmul(w[4], w[2]);
+    w[7] = cmul(w[4], w[3]);
+    w[8] = cmul(w[4], w[4]);
+    w[9] = cmul(w[8], w1);
+    w[10] = cmul(w[8], w[2]);
+    w[11] = cmul(w[8], w[3]);
+    w[12] = cmul(w[8], w[4]);
+    w[13] = cmul(w[8], w[5]);
+    w[14] = cmul(w[8], w[6]);
+    w[15] = cmul(w[8], w[7]);
 }
 
 // v[j] = x[tid + 256 j] on entry; on return X[tid + 256 k2] is in v[rev16(k2)].
@@ -61,11 +94,26 @@ __device__ __forceinline__ void f4k_transform(cf (&v)[16], float2* __restrict__ 
                                               int tid) {
     // ---- pass 1: DFT-16 over n2, times W4096^(r k0) = tw4k[k0][n0] * tw256[k0][n1] ----
     radix16(v);
+#if F4K_TWCHAIN
+    {
+        cf w[16], w1 = A.w1_4096;
+        asm volatile("" : "+v"(w1.x), "+v"(w1.y));  // opaque: keep the tree inside the frame loop (no LICM into 30 VGPRs)
+        pow_tree(w1, w);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
+    }
+#else
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
         float2 wa = tw4k[16 * k + A.lo], wb = tw256[16 * k + A.hi];
         v[rev16(k)] = cmul(v[rev16(k)], cmul(cf{wa.x, wa.y}, cf{wb.x, wb.y}));
     }
+#endif
+#if F4K_ABLATE == 1
+    radix16(v);
+    radix16(v);
+    return;
+#endif
     __syncthreads();  // previous transform's pass-3 reads are done
 #pragma unroll
     for (int k = 0; k < 16; ++k)
@@ -78,11 +126,21 @@ __device__ __forceinline__ void f4k_transform(cf (&v)[16], float2* __restrict__ 
         v[j] = cf{t.x, t.y};
     }
     radix16(v);
+#if F4K_TWCHAIN
+    {
+        cf w[16], w1 = A.w1_256;
+        asm volatile("" : "+v"(w1.x), "+v"(w1.y));
+        pow_tree(w1, w);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
+    }
+#else
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
         float2 w = tw256[16 * k + A.lo];
         v[rev16(k)] = cmul(v[rev16(k)], cf{w.x, w.y});
     }
+#endif
     __syncthreads();  // exchange-1 reads are done
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[A.x2w + 16 * k] = make_float2(v[rev16(k)].x, v[rev16(k)].y);

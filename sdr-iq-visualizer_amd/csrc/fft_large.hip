@@ -26,8 +26,8 @@ __global__ __launch_bounds__(F4K_THREADS, 2) void fft_large_rows_kernel(
     float2* __restrict__ tw256 = lds + F4K_XCH_ELEMS;
     float2* __restrict__ tw4k = tw256 + 256;
     const int tid = threadIdx.x;
-    const F4kAddr A = f4k_addr(tid);
-    f4k_init_tables(tw256, tw4k, tw4096, tid);
+    F4kAddr A = f4k_addr(tid);
+    f4k_init_tables(tw256, tw4k, tw4096, tid, A);
     __syncthreads();
 
     // XCD-aware persistent schedule: blocks with equal blockIdx % 8 share an

@@ -40,6 +40,15 @@ __device__ __forceinline__ float logpsd_db(float re, float im, float eps) {
     return __builtin_amdgcn_logf(mag + eps) * 6.02059991327962390427f;  // log2 -> 20*log10
 }
 
+// Same value without the square root when the floor cannot change the float32
+// sum: for |X| >= eps * 2^25, |X| + eps rounds to |X| (or its neighbour), so
+// 20*log10(|X| + eps) = 10*log10(|X|^2) to within half an ulp of |X|.  `thresh`
+// is (eps * 2^25)^2; the caller takes this path only when every lane of the
+// wave is above it (wave-uniform branch), else logpsd_db().
+__device__ __forceinline__ float logpsd_db_fast(float p) {
+    return __builtin_amdgcn_logf(p) * 3.01029995663981195213f;  // log2 -> 10*log10
+}
+
 hipError_t launch_fft4096(const LaunchArgs& a);
 hipError_t launch_fft_small(const LaunchArgs& a);   // 2 <= nfft <= 2048 (and 4096 for A/B)
 hipError_t launch_fft_large(const LaunchArgs& a);   // nfft > 4096 (multi-pass)

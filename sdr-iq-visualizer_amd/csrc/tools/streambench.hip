@@ -1,0 +1,97 @@
+// streambench.hip — what can a plain streaming kernel reach on this box with the
+// FFT path's traffic shape (8 B/sample read, 4 B/sample written)?  Developer tool.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+// frame = 4096 complex64 (32 KiB) in, 4096 float (16 KiB) out; one 256-thread WG per frame.
+// MODE 0: frames interleaved over blocks (f = b, b+G, ...); MODE 1: each block owns a contiguous chunk.
+template <int NT, int MODE, int DO_READ, int DO_WRITE>
+__global__ __launch_bounds__(256) void stream_k(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n_frames) {
+    size_t f0, f1, step;
+    if (MODE == 0) { f0 = blockIdx.x; f1 = n_frames; step = gridDim.x; }
+    else { size_t per = (n_frames + gridDim.x - 1) / gridDim.x; f0 = per * blockIdx.x; f1 = f0 + per < n_frames ? f0 + per : n_frames; step = 1; }
+    v4f acc = {0, 0, 0, 0};
+    for (size_t f = f0; f < f1; f += step) {
+        const v4f* x = in + f * 2048;
+        v4f* o = out + f * 1024;
+        v4f v[8];
+        if (DO_READ) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = NT ? __builtin_nontemporal_load(&x[threadIdx.x + 256 * j]) : x[threadIdx.x + 256 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v4f{(float)f, 1, 2, 3};
+        }
+        if (DO_WRITE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v4f r = v[2 * j] + v[2 * j + 1]; if (NT) __builtin_nontemporal_store(r, &o[threadIdx.x + 256 * j]); else o[threadIdx.x + 256 * j] = r; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+    }
+    if (!DO_WRITE && acc.x == 12345.678f) out[0] = acc;
+}
+
+// classic copy: n float4 in -> n float4 out, grid-stride
+template <int NT>
+__global__ __launch_bounds__(256) void copy_k(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        v4f v = NT ? __builtin_nontemporal_load(&in[i]) : in[i];
+        if (NT) __builtin_nontemporal_store(v, &out[i]); else out[i] = v;
+    }
+}
+
+template <class F>
+static float time_it(int reps, hipStream_t s, F launch) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) launch();
+    CK(hipStreamSynchronize(s));
+    std::vector<float> ms(reps);
+    for (int i = 0; i < reps; ++i) { CK(hipEventRecord(e0, s)); launch(); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[i], e0, e1)); }
+    std::sort(ms.begin(), ms.end());
+    return ms[reps / 2];
+}
+
+int main(int argc, char** argv) {
+    int lg = argc > 1 ? atoi(argv[1]) : 20, reps = argc > 2 ? atoi(argv[2]) : 10;
+    size_t nf = (size_t)1 << lg;
+    void *d_in, *d_out;
+    CK(hipMalloc(&d_in, nf * 4096 * 8)); CK(hipMalloc(&d_out, nf * 4096 * 8));   // out big enough for the 1:1 copy too
+    CK(hipMemset(d_in, 1, nf * 4096 * 8)); CK(hipMemset(d_out, 0, nf * 4096 * 8));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    printf("frames=2^%d (%.1f GiB in, %.1f GiB out)\n", lg, nf * 32768.0 / (1 << 30), nf * 16384.0 / (1 << 30));
+    const v4f* in = (const v4f*)d_in; v4f* out = (v4f*)d_out;
+    for (int bpc : {2, 3, 4, 6, 8}) {
+        unsigned g = cus * bpc;
+        double rw = 12.0 * nf * 4096, ro = 8.0 * nf * 4096, wo = 4.0 * nf * 4096;
+        float t;
+        t = time_it(reps, s, [&] { hipLaunchKernelGGL((stream_k<1, 0, 1, 1>), dim3(g), dim3(256), 0, s, in, out, nf); });
+        printf("bpc %d  r+w nt interleaved   %8.3f ms %7.1f GB/s\n", bpc, t, rw / t / 1e6);
+        t = time_it(reps, s, [&] { hipLaunchKernelGGL((stream_k<0, 0, 1, 1>), dim3(g), dim3(256), 0, s, in, out, nf); });
+        printf("bpc %d  r+w plain interleaved %8.3f ms %7.1f GB/s\n", bpc, t, rw / t / 1e6);
+        t = time_it(reps, s, [&] { hipLaunchKernelGGL((stream_k<1, 1, 1, 1>), dim3(g), dim3(256), 0, s, in, out, nf); });
+        printf("bpc %d  r+w nt chunked        %8.3f ms %7.1f GB/s\n", bpc, t, rw / t / 1e6);
+        t = time_it(reps, s, [&] { hipLaunchKernelGGL((stream_k<1, 0, 1, 0>), dim3(g), dim3(256), 0, s, in, out, nf); });
+        printf("bpc %d  read-only nt          %8.3f ms %7.1f GB/s\n", bpc, t, ro / t / 1e6);
+        t = time_it(reps, s, [&] { hipLaunchKernelGGL((stream_k<1, 0, 0, 1>), dim3(g), dim3(256), 0, s, in, out, nf); });
+        printf("bpc %d  write-only nt         %8.3f ms %7.1f GB/s\n", bpc, t, wo / t / 1e6);
+    }
+    size_t n4 = nf * 2048;  // float4 count of the input
+    for (int bpc : {4, 8, 16}) {
+        unsigned g = cus * bpc;
+        float t = time_it(reps, s, [&] { hipLaunchKernelGGL((copy_k<0>), dim3(g), dim3(256), 0, s, in, out, n4); });
+        printf("copy float4 plain bpc %2d   %8.3f ms %7.1f GB/s (r+w)\n", bpc, t, 2.0 * n4 * 16 / t / 1e6);
+        t = time_it(reps, s, [&] { hipLaunchKernelGGL((copy_k<1>), dim3(g), dim3(256), 0, s, in, out, n4); });
+        printf("copy float4 nt    bpc %2d   %8.3f ms %7.1f GB/s (r+w)\n", bpc, t, 2.0 * n4 * 16 / t / 1e6);
+    }
+    return 0;
+}
