@@ -118,6 +118,8 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
         e = sdrk::launch_fft4096(a);
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
+    else if (sdrk::fft_tiled_supports(p->nfft))
+        e = sdrk::launch_fft_tiled(a);
     else
         e = sdrk::launch_fft_large(a);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
