@@ -47,7 +47,7 @@ template <bool HAS_WINDOW>
 __global__ __launch_bounds__(FT_THREADS, 3) void col256_kernel(
     const float2* __restrict__ iq, size_t frame_stride, float2* __restrict__ scratch, size_t n_frames,
     int M, const float* __restrict__ window, const float2* __restrict__ tw4096,
-    const float2* __restrict__ coarse, const float2* __restrict__ fine) {
+    const float2* __restrict__ t1 /* [m][p] = W_N^(m p) */, const float2* __restrict__ t2 /* [m][q] = W_N^(16 m q) */) {
     __shared__ float2 lds[4096 + 256];
     float2* __restrict__ tw256 = lds + 4096;  // [k][n] = W256^(n k)
     const int tid = threadIdx.x;
@@ -95,14 +95,19 @@ __global__ __launch_bounds__(FT_THREADS, 3) void col256_kernel(
             v[a] = cf{t.x, t.y};
         }
         radix16(v);  // -> q ; k3 = p + 16 q
+        // W_N^(m k3) = W_N^(m p) * W_N^(16 m q): one entry of t1 and the 128-byte row m of t2
+        // (16 lanes with consecutive m read 2 KiB contiguous; the four p of a wave broadcast).
         float2* __restrict__ o = scratch + f * nfft + m;
+        const float2 bw = t1[m * 16 + hi];
+        const cf base = cf{bw.x, bw.y};
+        const float4* __restrict__ row = reinterpret_cast<const float4*>(t2 + (size_t)m * 16);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k3 = hi + 16 * q;
-            const unsigned e = (unsigned)m * (unsigned)k3;  // < N <= 2^20
-            float2 cw = coarse[e >> 12], fw = fine[e & 4095];
-            cf z = cmul(v[rev16(q)], cmul(cf{cw.x, cw.y}, cf{fw.x, fw.y}));
-            o[(size_t)k3 * M] = make_float2(z.x, z.y);
+        for (int q2 = 0; q2 < 8; ++q2) {
+            const float4 w = row[q2];
+            cf z0 = cmul(v[rev16(2 * q2)], cmul(base, cf{w.x, w.y}));
+            cf z1 = cmul(v[rev16(2 * q2 + 1)], cmul(base, cf{w.z, w.w}));
+            o[(size_t)(hi + 32 * q2) * M] = make_float2(z0.x, z0.y);
+            o[(size_t)(hi + 32 * q2 + 16) * M] = make_float2(z1.x, z1.y);
         }
     }
 }
@@ -217,8 +222,8 @@ hipError_t launch_fft_tiled(const LaunchArgs& a) {
     const int R = a.nfft / 65536, M = 256 * R;
     const float2* iq = static_cast<const float2*>(a.d_iq);
     const float2* tw = static_cast<const float2*>(a.d_twiddle);
-    const float2* coarse = static_cast<const float2*>(a.d_twiddle_big);
-    const float2* fine = coarse + 1024;
+    const float2* t1 = static_cast<const float2*>(a.d_twiddle_big) + 1024 + 4096;  // after coarse, fine
+    const float2* t2 = t1 + (size_t)M * 16;
     float2* scratch = static_cast<float2*>(a.d_scratch);
     const size_t out_elem = a.epilogue == EPI_LOGPSD ? sizeof(float) : sizeof(float2);
     const size_t max_blocks = (size_t)a.num_cus * 3;
@@ -231,10 +236,10 @@ hipError_t launch_fft_tiled(const LaunchArgs& a) {
             const float2* src = iq + f0 * a.frame_stride;
             if (a.d_window)
                 hipLaunchKernelGGL((col256_kernel<true>), dim3(grid), dim3(FT_THREADS), 0, a.stream, src,
-                                   a.frame_stride, scratch, nf, M, a.d_window, tw, coarse, fine);
+                                   a.frame_stride, scratch, nf, M, a.d_window, tw, t1, t2);
             else
                 hipLaunchKernelGGL((col256_kernel<false>), dim3(grid), dim3(FT_THREADS), 0, a.stream, src,
-                                   a.frame_stride, scratch, nf, M, a.d_window, tw, coarse, fine);
+                                   a.frame_stride, scratch, nf, M, a.d_window, tw, t1, t2);
         }
         if (R > 1) {
             size_t cols = nf * 65536;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -310,13 +311,25 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
     }
     if (nfft > 4096) {
         const int n1 = nfft / 4096;
-        std::vector<float2> t(1024 + 4096);
+        const bool tiled = sdrk::fft_tiled_supports(nfft);
+        const int M = tiled ? nfft / 256 : 0;   // tiled plans: [m][p] = W_N^(m p), [m][q] = W_N^(16 m q)
+        std::vector<float2> t(1024 + 4096 + (size_t)2 * M * 16);
         for (int m = 0; m < 1024; ++m) t[m] = twiddle(m % n1, n1);           // coarse: W_N1^m = W_N^(4096 m)
         for (int m = 0; m < 4096; ++m) t[1024 + m] = twiddle(m, (double)nfft);  // fine: W_N^m
+        for (int m = 0; m < M; ++m)
+            for (int k = 0; k < 16; ++k) {
+                t[1024 + 4096 + (size_t)m * 16 + k] = twiddle((double)m * k, (double)nfft);
+                t[1024 + 4096 + (size_t)M * 16 + (size_t)m * 16 + k] = twiddle(16.0 * m * k, (double)nfft);
+            }
         PLAN_TRY(hipMalloc((void**)&p->d_tw_big, sizeof(float2) * t.size()));
         PLAN_TRY(hipMemcpy(p->d_tw_big, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
         // scratch: up to 128 MiB of complex64 frames (stays in the 256 MiB Infinity Cache)
-        size_t frames = ((size_t)128 << 20) / ((size_t)nfft * sizeof(float2));
+        size_t scratch_mb = 128;
+        if (const char* env = getenv("SDRK_SCRATCH_MB")) {  // tuning knob (developer use)
+            long v = atol(env);
+            if (v >= 1 && v <= 65536) scratch_mb = (size_t)v;
+        }
+        size_t frames = (scratch_mb << 20) / ((size_t)nfft * sizeof(float2));
         if (frames < 1) frames = 1;
         if (frames > max_batch) frames = max_batch;
         p->scratch_frames = frames;
