@@ -107,11 +107,19 @@ def main():
     from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
 
     dist = None
-    if world > 1:
+    n_dev = torch.cuda.device_count()
+    dev = local_rank % max(n_dev, 1)
+    # One rank per GPU over RCCL ("nccl").  Rehearsal on a box with fewer GPUs than ranks
+    # (ranks then share a device, which RCCL refuses): gloo carries the barrier/max-reduce.
+    backend = "nccl" if n_dev >= world else "gloo"
+    if "RANK" in os.environ:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     lib = _ffi.lib()
     _ffi.require_device(dev)
 
@@ -139,7 +147,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, kernel_ms], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
@@ -157,7 +165,7 @@ def main():
             mg, mr = 10.0 ** (row.astype(np.float64) / 20), 10.0 ** (ref.astype(np.float64) / 20)
             parity = max(parity, float(np.abs(mg - mr).max() / mr.max()))
     if dist is not None:
-        t = torch.tensor([parity], device="cuda", dtype=torch.float64)
+        t = torch.tensor([parity], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         parity = float(t[0])
 
@@ -200,6 +208,7 @@ def main():
                             + ("; configs[3] frame-range sharding" if world > 1 else "") + ")",
                 "nfft": NFFT, "frames_per_gpu": frames, "window": args.window,
                 "sharding": f"frame-range x{world}, no collectives", "device": info,
+                "rendezvous_backend": (backend if dist is not None else None),
             },
             "hbm_peak_frac": round(value * 1e6 * ALGO_BYTES_PER_SAMPLE / 1e9 / (HBM_PEAK_GBPS * world), 4),
             "roofline": {
