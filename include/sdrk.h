@@ -112,6 +112,14 @@ int sdrk_exec_device(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames,
 int sdrk_exec_fft_host(sdrk_plan* plan, const void* iq_c64, size_t n_frames,
                        size_t frame_stride, void* out_c64);
 
+/* Averaged periodogram (Welch, no detrend): out_psd[k] = scale * sum_f |fft(w*x_f)|^2[k]
+ * over n_frames frames cut from one host stream at spacing frame_stride, in the plan's
+ * shift order.  With scale = 1/(n_frames * Fs * sum(w^2)) this is matplotlib's
+ * mlab.psd(..., window=hanning, noverlap=nfft-frame_stride) as plotted by the reference's
+ * offline script (scripts/process_sigmf_data.py:188-189).  out_psd: nfft float32. */
+int sdrk_welch_psd_host(sdrk_plan* plan, const void* iq_c64, size_t n_frames, size_t frame_stride,
+                        float scale, float* out_psd);
+
 /* Block until everything queued on the plan's own stream has finished. */
 int sdrk_plan_sync(sdrk_plan* plan);
 

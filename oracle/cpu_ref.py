@@ -78,6 +78,24 @@ def stft_db(iq, nfft, hop, window=None, eps=1e-12, shift=True):
     return out
 
 
+def welch_psd(iq, nfft, sample_rate, hop=None, window=None, shift=True):
+    """matplotlib ``mlab.psd(x, NFFT, Fs, window=hanning, noverlap=NFFT-hop)`` for complex
+    input (two-sided, no detrend, scale_by_freq): the quantity the reference's offline script
+    plots at scripts/process_sigmf_data.py:188-189 (``plt.psd`` = 10*log10 of it).
+    mean over the 1+(L-NFFT)//hop full segments of |fft(w*seg)|^2 / (Fs * sum(w^2)),
+    rolled so that DC sits at index NFFT/2."""
+    x = np.asarray(iq).reshape(-1)
+    hop = nfft if hop is None else hop
+    w = np.hanning(nfft) if window is None else np.asarray(window, dtype=np.float64)
+    rows = 1 + (x.shape[0] - nfft) // hop
+    acc = np.zeros(nfft, dtype=np.float64)
+    for r in range(rows):
+        seg = x[r * hop: r * hop + nfft].astype(np.complex128) * w
+        acc += np.abs(np.fft.fft(seg)) ** 2
+    pxx = acc / rows / (sample_rate * np.sum(w ** 2))
+    return np.fft.fftshift(pxx) if shift else pxx
+
+
 class Waterfall:
     """app/dashboard/callbacks.py:19,176,182: ``deque(maxlen=100)``, ``append(power_db)``,
     ``np.array(deque)`` — rows oldest first; y axis = range(len) (:186)."""

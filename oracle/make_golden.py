@@ -136,6 +136,18 @@ def main():
         store[f"n{n}/freqs_ends"] = d["freqs"][[0, n // 2, -1]]
     np.savez_compressed(os.path.join(OUT, "ref_large_sampled.npz"), **store)
 
+    # ---- offline Welch PSD: what plt.psd at scripts/process_sigmf_data.py:188-189 computes ----
+    # (matplotlib is a third-party library, not reference code; the script itself needs the
+    # absent `sigmf` package, so its psd call is made directly with the script's arguments.)
+    from matplotlib import mlab
+    x = (synth.synth_iq(seed=11, first_frame=0, n_frames=40, nfft=1024).reshape(-1) * np.float32(1 / 2048)
+         + synth.tone(40 * 1024, 40 * 1024 * 0.1037, amplitude=2.0)).astype(np.complex64)
+    fs = 2_000_000.0
+    pxx, f = mlab.psd(x.astype(np.complex128), NFFT=1024, Fs=fs)          # defaults: hanning, noverlap=0
+    pxx_ov, _ = mlab.psd(x.astype(np.complex128), NFFT=1024, Fs=fs, noverlap=512)
+    np.savez_compressed(os.path.join(OUT, "ref_welch.npz"), iq=x, fs=np.array([fs]), pxx=pxx, freqs=f,
+                        pxx_noverlap512=pxx_ov)
+
     # ---- waterfall: the reference's deque semantics (callbacks.py:19,176,182) ----
     # The callback module needs dash/plotly and a live streamer, so the deque lines
     # are exercised directly: 103 appends into deque(maxlen=100) -> rows 3..102.

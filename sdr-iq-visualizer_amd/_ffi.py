@@ -62,6 +62,7 @@ SYMBOLS = [
     ("sdrk_exec_host", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     ("sdrk_exec_device", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     ("sdrk_exec_fft_host", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    ("sdrk_welch_psd_host", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_void_p]),
     ("sdrk_plan_sync", c_int, [c_void_p]),
     ("sdrk_exec_device_timed", c_int,
      [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float)]),

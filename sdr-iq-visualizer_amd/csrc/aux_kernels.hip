@@ -51,4 +51,31 @@ hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frame
     return hipGetLastError();
 }
 
+// Welch-style averaged periodogram: out[k] = scale * sum_f |X[f][k]|^2 over the
+// complex spectra of n_frames frames (column sums; thread k walks down its column,
+// consecutive threads read consecutive bins).  Used by the offline PSD of the SigMF
+// CLI (reference: plt.psd at scripts/process_sigmf_data.py:188-189 = matplotlib
+// mlab.psd: mean of |FFT(w x)|^2 over segments / (Fs * sum w^2)).
+__global__ __launch_bounds__(256) void power_mean_kernel(const float2* __restrict__ X, size_t n_frames,
+                                                         int nfft, float scale, float* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nfft) return;
+    float acc = 0.0f, comp = 0.0f;  // Kahan: thousands of segments of equal magnitude
+    for (size_t f = 0; f < n_frames; ++f) {
+        const float2 z = X[f * (size_t)nfft + k];
+        const float p = fmaf(z.x, z.x, z.y * z.y) - comp;
+        const float t = acc + p;
+        comp = (t - acc) - p;
+        acc = t;
+    }
+    out[k] = acc * scale;
+}
+
+hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(power_mean_kernel, dim3((nfft + 255) / 256), dim3(256), 0, stream,
+                       static_cast<const float2*>(d_spec), n_frames, nfft, scale, d_out);
+    return hipGetLastError();
+}
+
 }  // namespace sdrk

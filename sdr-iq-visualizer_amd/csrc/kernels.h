@@ -57,4 +57,7 @@ hipError_t launch_fft_tiled(const LaunchArgs& a);   // tiled 256 x R x 256 passe
 hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,
                              void* d_iq, hipStream_t stream);
 
+hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,
+                             hipStream_t stream);
+
 }  // namespace sdrk

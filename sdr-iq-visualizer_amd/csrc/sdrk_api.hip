@@ -369,6 +369,42 @@ int sdrk_exec_fft_host(sdrk_plan* p, const void* iq, size_t n_frames, size_t fra
     return exec_host_common(p, iq, n_frames, frame_stride, out_c64, sdrk::EPI_COMPLEX);
 }
 
+int sdrk_welch_psd_host(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride,
+                        float scale, float* out_psd) {
+    int st = check_exec_args(p, iq, n_frames, frame_stride, out_psd);
+    if (st != SDRK_OK) return st;
+    if (n_frames == 0) return fail(SDRK_ERR_INVALID, "welch needs at least one frame");
+    if (n_frames > p->max_batch)
+        return fail(SDRK_ERR_INVALID, "n_frames %zu exceeds the plan's max_batch %zu", n_frames, p->max_batch);
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t nfft = (size_t)p->nfft;
+    const size_t in_bytes = ((n_frames - 1) * frame_stride + nfft) * sizeof(float2);
+    // spectra are produced in chunks into d_out; the column sums accumulate per chunk on the host side
+    // of the call only through `scale` (each chunk adds scale * sum), so one small device row suffices.
+    const size_t chunk = ((size_t)256 << 20) / (nfft * sizeof(float2)) ? ((size_t)256 << 20) / (nfft * sizeof(float2)) : 1;
+    const size_t spec_frames = n_frames < chunk ? n_frames : chunk;
+    st = grow(p->device, &p->d_in, &p->in_cap, in_bytes);
+    if (st != SDRK_OK) return st;
+    st = grow(p->device, &p->d_out, &p->out_cap, spec_frames * nfft * sizeof(float2) + nfft * sizeof(float));
+    if (st != SDRK_OK) return st;
+    float* d_row = reinterpret_cast<float*>(static_cast<char*>(p->d_out) + spec_frames * nfft * sizeof(float2));
+    HIP_TRY(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
+    std::vector<float> row(nfft), total(nfft, 0.0f);
+    for (size_t f0 = 0; f0 < n_frames; f0 += spec_frames) {
+        const size_t nf = n_frames - f0 < spec_frames ? n_frames - f0 : spec_frames;
+        st = plan_launch(p, static_cast<const float2*>(p->d_in) + f0 * frame_stride, nf, frame_stride, p->d_out,
+                         sdrk::EPI_COMPLEX, p->stream);
+        if (st != SDRK_OK) return st;
+        hipError_t e = sdrk::launch_power_mean(p->d_out, nf, p->nfft, scale, d_row, p->stream);
+        if (e != hipSuccess) return fail(SDRK_ERR_HIP, "power_mean launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(row.data(), d_row, nfft * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (size_t k = 0; k < nfft; ++k) total[k] += row[k];   // <= a handful of chunks
+    }
+    memcpy(out_psd, total.data(), nfft * sizeof(float));
+    return SDRK_OK;
+}
+
 int sdrk_exec_device(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride,
                      float* d_out_db, void* stream) {
     int st = check_exec_args(p, d_iq, n_frames, frame_stride, d_out_db);

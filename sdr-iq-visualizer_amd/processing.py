@@ -7,7 +7,7 @@ the waterfall at app/dashboard/callbacks.py:176-182.  A maintainer switching to
 this build imports these names there (INTEGRATION.md shows the three-line
 change); the Dash callbacks keep reading the same ``plot_data`` dict.
 """
-from .spectrum import fft_c64, freq_axis, process_frame, spectrum_db, stft_db  # noqa: F401
+from .spectrum import fft_c64, freq_axis, process_frame, spectrum_db, stft_db, welch_psd  # noqa: F401
 from .waterfall import WaterfallBuffer  # noqa: F401
 
-__all__ = ["spectrum_db", "fft_c64", "freq_axis", "process_frame", "stft_db", "WaterfallBuffer"]
+__all__ = ["spectrum_db", "fft_c64", "freq_axis", "process_frame", "stft_db", "welch_psd", "WaterfallBuffer"]

@@ -170,6 +170,33 @@ class SpectrumPlan:
             self._run_host(lib().sdrk_exec_host, x, rows, hop, out)
         return out
 
+    def welch_psd(self, iq, sample_rate: float, hop: Optional[int] = None) -> np.ndarray:
+        """Averaged periodogram of one contiguous stream, float32 ``(nfft,)``:
+        ``mean_r |fft(w * x_r)|^2 / (sample_rate * sum(w^2))`` over the
+        ``1 + (len - nfft)//hop`` full segments — matplotlib's ``mlab.psd`` (no detrend,
+        two-sided; in fftshift order when the plan shifts), which is what the reference's
+        offline script plots (scripts/process_sigmf_data.py:188-189).  The per-segment
+        transforms and the averaging both run on the GPU."""
+        x = _as_c64(iq).reshape(-1)
+        hop = self.nfft if hop is None else int(hop)
+        if hop < 1:
+            raise ValueError("hop must be >= 1")
+        if x.shape[0] < self.nfft:
+            raise ValueError(f"stream of {x.shape[0]} samples is shorter than one {self.nfft}-sample segment")
+        rows = 1 + (x.shape[0] - self.nfft) // hop
+        if self._wkey == "rect":
+            wss = float(self.nfft)
+        elif self._wkey == "hann":
+            wss = float(np.sum(np.hanning(self.nfft) ** 2))
+        else:
+            wss = float(np.sum(np.frombuffer(self._wkey[1], dtype=np.float32).astype(np.float64) ** 2))
+        scale = 1.0 / (rows * float(sample_rate) * wss)
+        out = np.empty(self.nfft, dtype=np.float32)
+        with self._lock:
+            check(lib().sdrk_welch_psd_host(self.handle, x.ctypes.data_as(c_void_p), c_size_t(rows), c_size_t(hop),
+                                            c_float(scale), out.ctypes.data_as(c_void_p)))
+        return out
+
     # -- device pointers (bench / pipelines that keep data resident) -------------
     def exec_device(self, d_iq: int, n_frames: int, d_out: int, *, frame_stride: Optional[int] = None,
                     stream: int = 0) -> None:
@@ -282,6 +309,14 @@ def process_frame(samples, sample_rate: float, center_freq: float, *, window: Wi
         "sample_rate": sample_rate,
         "center_freq": center_freq,
     }
+
+
+def welch_psd(iq, nfft: int, sample_rate: float, hop: Optional[int] = None, window: WindowArg = "hann", *,
+              shift: bool = True, device: int = 0) -> np.ndarray:
+    """Linear two-sided PSD (power per Hz) as ``matplotlib.mlab.psd`` computes it for the
+    reference's offline plots (scripts/process_sigmf_data.py:188-189: NFFT=1024, Hann,
+    noverlap=0).  Returns float32 ``(nfft,)`` in fftshift order (use ``freq_axis`` for x)."""
+    return _cached_plan(int(nfft), window, 1e-12, shift, device).welch_psd(iq, sample_rate, hop)
 
 
 def stft_db(iq, nfft: int, hop: Optional[int] = None, window: WindowArg = None, *, eps: float = 1e-12,

@@ -23,6 +23,7 @@ from .spectrum import (  # noqa: E402
     process_frame,
     spectrum_db,
     stft_db,
+    welch_psd,
 )
 from .waterfall import WaterfallBuffer  # noqa: E402
 from ._ffi import SdrkError, device_count, device_info, library_path  # noqa: E402
@@ -39,4 +40,5 @@ __all__ = [
     "process_frame",
     "spectrum_db",
     "stft_db",
+    "welch_psd",
 ]

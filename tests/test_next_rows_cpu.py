@@ -1,0 +1,135 @@
+"""CPU: the "next" rows of SURVEY.md §8f that are host logic — SigMF cf32_le I/O (f3) and
+the reader-loop shim's queue / error behaviour (f2, with the oracle injected as the per-frame
+transform: there is no GPU here) — plus the Welch restatement pinned to matplotlib's mlab.psd."""
+import io
+import json
+import time
+import zipfile
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from sdr_iq_visualizer_amd import sigmf_io, streaming, synth
+
+
+def test_oracle_welch_matches_mlab_psd(golden):
+    g = golden["ref_welch"]
+    fs = float(g["fs"][0])
+    p = cpu_ref.welch_psd(g["iq"], 1024, fs)
+    assert np.abs(p - g["pxx"]).max() <= 1e-12 * g["pxx"].max()
+    p2 = cpu_ref.welch_psd(g["iq"], 1024, fs, hop=512)
+    assert np.abs(p2 - g["pxx_noverlap512"]).max() <= 1e-12 * g["pxx"].max()
+    assert np.array_equal(cpu_ref.freq_axis(1024, fs, 0.0), g["freqs"])
+
+
+def test_sigmf_roundtrip_and_metadata_keys(tmp_path):
+    x = synth.synth_iq(3, 0, 2, 4096).reshape(-1)
+    data, meta = sigmf_io.write_sigmf(str(tmp_path / "rec"), x, 1_000_000, 2_400_000_000)
+    assert data.endswith(".sigmf-data") and meta.endswith(".sigmf-meta")
+    m = json.load(open(meta))
+    # keys the reference's exporter writes (app/dashboard/callbacks.py:285-304)
+    assert m["global"]["core:datatype"] == "cf32_le" and m["global"]["core:sample_rate"] == 1_000_000
+    assert m["global"]["core:version"] == "1.0.0" and m["annotations"] == []
+    assert m["captures"][0]["core:frequency"] == 2_400_000_000 and m["captures"][0]["core:sample_start"] == 0
+    raw = np.fromfile(data, dtype="<f4")
+    assert raw.size == 2 * x.size and raw[0] == x[0].real and raw[1] == x[0].imag     # interleaved I,Q
+    for path in (meta, data, str(tmp_path / "rec")):
+        y, info = sigmf_io.read_sigmf(path)
+        assert y.dtype == np.complex64 and np.array_equal(y, x)
+        assert info["sample_rate"] == 1_000_000.0 and info["center_freq"] == 2_400_000_000.0
+    y, _ = sigmf_io.read_sigmf(meta, max_samples=100)
+    assert np.array_equal(y, x[:100])
+
+
+def test_sigmf_zip_as_the_dashboard_exports_it(tmp_path):
+    x = synth.synth_iq(4, 0, 1, 4096)[0].astype(np.complex128)      # the app holds complex128 samples
+    blob = sigmf_io.to_zip_bytes(x, 1_000_000, 2_400_000_000)
+    with zipfile.ZipFile(io.BytesIO(blob)) as z:
+        names = sorted(z.namelist())
+    assert names == ["sdr_sample.sigmf-data", "sdr_sample.sigmf-meta"]
+    p = tmp_path / "dl.zip"
+    p.write_bytes(blob)
+    y, info = sigmf_io.read_sigmf(str(p))
+    assert np.array_equal(y, x.astype(np.complex64)) and info["center_freq"] == 2.4e9
+
+
+def test_sigmf_integer_datatypes_and_errors(tmp_path):
+    base = str(tmp_path / "i16")
+    iq = np.array([1, -2, 3, -4, 5, -6], dtype="<i2")
+    iq.tofile(base + ".sigmf-data")
+    json.dump({"global": {"core:datatype": "ci16_le", "core:sample_rate": 48000}, "captures": [{}]},
+              open(base + ".sigmf-meta", "w"))
+    y, info = sigmf_io.read_sigmf(base)
+    assert np.array_equal(y, np.array([1 - 2j, 3 - 4j, 5 - 6j], dtype=np.complex64)) and info["center_freq"] == 0.0
+    json.dump({"global": {"core:datatype": "rf32_le"}}, open(base + ".sigmf-meta", "w"))
+    with pytest.raises(ValueError):
+        sigmf_io.read_sigmf(base)
+
+
+def _oracle_compute(samples, fs, fc):
+    return cpu_ref.process_frame(samples, fs, fc)
+
+
+def test_streamer_shim_fifo_and_drop_oldest():
+    src = streaming.SyntheticSource(nfft=256, seed=5, tone_bin=None)
+    s = streaming.SpectrumStreamer(src, 2_000_000, 915_000_000, queue_size=4, compute=_oracle_compute)
+    assert s.is_connected() and s.get_latest_data() is None
+    for i in range(7):                                   # drive the loop body by hand: 7 pushes into 4 slots
+        s._push({"i": i})
+    assert [s.get_latest_data()["i"] for _ in range(4)] == [3, 4, 5, 6]       # oldest dropped, FIFO pop
+    assert s.get_latest_data() is None
+    assert s.start_streaming()
+    deadline = time.time() + 5
+    while s.total_frames < 6 and time.time() < deadline:
+        time.sleep(0.01)
+    s.stop_streaming()
+    st = s.get_status()
+    assert st["total_frames"] >= 6 and st["queue_size"] == 4 and not st["running"]
+    d = s.get_latest_data()
+    assert list(d) == ["time", "samples", "freqs", "power_db", "sample_rate", "center_freq"]
+    assert d["power_db"].shape == (256,) and d["freqs"][128] == 915_000_000.0
+
+
+def test_streamer_shim_stops_after_three_consecutive_errors(monkeypatch):
+    class Broken:
+        calls = 0
+
+        def rx(self):
+            Broken.calls += 1
+            raise OSError(110, "timed out")
+
+    monkeypatch.setattr(streaming.time, "sleep", lambda s: None)
+    s = streaming.SpectrumStreamer(Broken(), compute=_oracle_compute)
+    s.running = True
+    s._stream_data()                                     # returns by itself
+    assert Broken.calls == 3 and not s.running and s.total_frames == 0
+
+    class Flaky:                                         # one failure, then fine: counter resets
+        n = 0
+
+        def rx(self):
+            Flaky.n += 1
+            if Flaky.n in (2, 4):
+                raise ValueError("glitch")
+            if Flaky.n >= 8:
+                s2.running = False
+            return synth.synth_iq(1, Flaky.n, 1, 64)[0]
+
+    s2 = streaming.SpectrumStreamer(Flaky(), compute=_oracle_compute)
+    s2.running = True
+    s2._stream_data()
+    assert s2.total_frames == 6                          # 8 reads, 2 failed, never 3 in a row
+
+
+def test_sigmf_source_cuts_and_loops(tmp_path):
+    x = synth.synth_iq(8, 0, 3, 64).reshape(-1)
+    sigmf_io.write_sigmf(str(tmp_path / "r"), x, 1e6, 0)
+    src = streaming.SigMFSource(str(tmp_path / "r.sigmf-meta"), nfft=64)
+    frames = [src.rx() for _ in range(4)]
+    assert np.array_equal(frames[0], x[:64]) and np.array_equal(frames[2], x[128:]) and np.array_equal(frames[3], x[:64])
+    src2 = streaming.SigMFSource(str(tmp_path / "r"), nfft=64, loop=False)
+    for _ in range(3):
+        src2.rx()
+    with pytest.raises(EOFError):
+        src2.rx()

@@ -306,3 +306,63 @@ def test_thread_per_device_sharding_single_gpu(pkg):
     out = sharding.spectrum_db_sharded(x, [0, 0])
     assert_db_parity(out, cpu_ref.spectrum_db(x))
     assert np.array_equal(out, pkg.spectrum_db(x, devices=[0]))
+
+
+# ---- "next" rows on the GPU ------------------------------------------------
+
+def test_welch_psd_vs_mlab_golden(pkg, golden):
+    """Offline PSD of scripts/process_sigmf_data.py:188-189 (mlab.psd, NFFT=1024, Hann)."""
+    g = golden["ref_welch"]
+    fs = float(g["fs"][0])
+    for hop, key in ((None, "pxx"), (512, "pxx_noverlap512")):
+        got = pkg.welch_psd(g["iq"], 1024, fs, hop=hop)
+        assert got.dtype == np.float32 and got.shape == (1024,)
+        assert np.abs(got - g[key]).max() <= 1e-5 * g[key].max()
+    rect = pkg.welch_psd(g["iq"], 256, fs, window=None)
+    assert np.abs(rect - cpu_ref.welch_psd(g["iq"], 256, fs, window=np.ones(256))).max() <= 1e-5 * rect.max()
+    with pytest.raises(ValueError):
+        pkg.welch_psd(g["iq"][:100], 1024, fs)
+
+
+def test_config1_sigmf_cli_end_to_end(pkg, tmp_path, capsys):
+    """BASELINE.json config 1: one 4096-point PSD of a recorded SigMF file (plumbing)."""
+    import json
+    from sdr_iq_visualizer_amd import cli, sigmf_io, synth
+    base = str(tmp_path / "rec")
+    assert cli.main(["synth", base, "--frames", "8", "--nfft", "4096"]) == 0
+    capsys.readouterr()
+    out = str(tmp_path / "psd.npz")
+    assert cli.main(["psd", base + ".sigmf-meta", "--nfft", "4096", "--welch", "1024", "--out", out]) == 0
+    report = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    samples, meta = sigmf_io.read_sigmf(base)
+    assert report["samples"] == 8 * 4096 and report["sample_rate"] == 1_000_000.0
+    z = np.load(out)
+    assert_db_parity(z["power_db"], cpu_ref.spectrum_db(samples[:4096]), what="cli psd")
+    assert np.array_equal(z["freqs"], cpu_ref.freq_axis(4096, 1_000_000.0, 2_400_000_000.0))
+    ref = cpu_ref.welch_psd(samples, 1024, 1_000_000.0)
+    assert np.abs(z["welch_pxx"] - ref).max() <= 1e-5 * ref.max()
+    assert np.array_equal(samples.reshape(8, 4096), synth.synth_iq(1234, 0, 8, 4096))
+
+
+def test_streamer_shim_on_gpu(pkg):
+    """The reader loop with the GPU transform: dicts as the dashboard reads them."""
+    import time
+    from sdr_iq_visualizer_amd import streaming, synth
+    s = streaming.SpectrumStreamer(streaming.SyntheticSource(nfft=4096, seed=77, tone_bin=512.0), queue_size=100)
+    assert s.start_streaming()
+    deadline = time.time() + 20
+    while s.total_frames < 20 and time.time() < deadline:
+        time.sleep(0.01)
+    s.stop_streaming()
+    assert s.total_frames >= 20
+    first = s.get_latest_data()                                   # FIFO: frame 0
+    x0 = (synth.synth_iq(77, 0, 1, 4096)[0] + synth.tone(4096, 512.0, 400.0)).astype(np.complex64)
+    assert np.array_equal(first["samples"], x0)
+    assert_db_parity(first["power_db"], cpu_ref.spectrum_db(x0), what="streamer frame 0")
+    assert int(np.argmax(first["power_db"])) == 2048 + 512
+    wf = pkg.WaterfallBuffer(4096, maxlen=100)                    # callbacks.py:176-182 on top of it
+    n = 0
+    while (d := s.get_latest_data()) is not None:
+        wf.append(d["power_db"])
+        n += 1
+    assert len(wf) == min(n, 100) and wf.as_array().shape == (len(wf), 4096)
