@@ -139,6 +139,29 @@ int sdrk_exec_device_timed(sdrk_plan* plan, const void* d_iq_c64, size_t n_frame
 int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_frames,
                     int nfft, void* d_iq_c64, void* stream);
 
+/* ---- per-row reductions for the spectrum's first consumer ------------------
+ * The O(N) measurements of the reference's classifier helpers
+ * (app/processing/classifier.py:163-212) computed next to the rows, so that a
+ * consumer needs ~20 scalars per row instead of the row.  `rows` is n_rows*nfft
+ * float32, on the host (rows_on_device = 0) or already on `device` (non-zero, e.g.
+ * the output of sdrk_exec_device).
+ *
+ * sdrk_row_stats: out[r*16 + i] (double), i =
+ *   0 max | 1 sorted[rank] | 2 sorted[rank+1] (order statistics of the row, for the
+ *   percentile noise floor, classifier.py:179-181) | 3 mean | 4 mean (x-mean)^2 |
+ *   5 mean (x-mean)^4 (:191-198) | 6 mean ln p | 7 mean p, p = max(10^(x/10), 1e-15)
+ *   (:183-189) | 8,9 first,last index with x >= max-3 | 10,11 ... max-10 | 12,13 ...
+ *   max-20 (:163-170) | 14 argmax | 15 nfft.
+ * sdrk_row_peaks: strict local maxima above thresholds[r], accepted left to right
+ *   when >= min_distance bins after the previous accepted one (:200-212).
+ *   out_idx: n_rows*max_peaks int32 (first max_peaks peaks of each row),
+ *   out_count: n_rows int32 (may exceed max_peaks: the total found). */
+int sdrk_row_stats(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft,
+                   int rank, double* out);
+int sdrk_row_peaks(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft,
+                   const double* thresholds, int min_distance, int max_peaks, int32_t* out_idx,
+                   int32_t* out_count);
+
 /* ---- waterfall ring -------------------------------------------------------
  * Replaces deque(maxlen=100) / append / np.array(deque) at
  * dashboard/callbacks.py:19,176,182: a device-resident ring of the last

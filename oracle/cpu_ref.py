@@ -96,6 +96,38 @@ def welch_psd(iq, nfft, sample_rate, hop=None, window=None, shift=True):
     return np.fft.fftshift(pxx) if shift else pxx
 
 
+def row_features(freqs, power_db):
+    """The measurements classify_signal_advanced makes before its rule ladder
+    (app/processing/classifier.py:45-60), restated helper by helper (:163-219)."""
+    x = np.asarray(power_db)
+    n = len(x)
+    noise_floor_db = float(np.percentile(x, 20))                              # :179-181
+    snr_db = float(np.max(x) - noise_floor_db)                                # :46
+
+    def obw(drop):                                                            # :163-170
+        mask = x >= np.max(x) - float(drop)
+        occ = np.asarray(freqs)[mask]
+        return float(occ[-1] - occ[0]) if np.any(mask) else 0.0
+
+    p = np.clip(np.power(10.0, np.asarray(x, dtype=float) / 10.0), 1e-15, None)   # :184-186
+    sfm = float(np.clip(float(np.exp(np.mean(np.log(p)))) / float(np.mean(p)), 0.0, 1.0))
+    xf = np.asarray(x, dtype=float)                                           # :191-198
+    mu, sigma = float(np.mean(xf)), float(np.std(xf))
+    kurt = 0.0 if sigma < 1e-9 else float(np.mean(((xf - mu) / sigma) ** 4))
+    thr = max(noise_floor_db + 5.0, np.max(x) - 0.9 * snr_db + 5.0)           # :55
+    min_dist = max(3, n // 300)                                               # :56
+    peaks, last = [], -min_dist                                               # :200-212
+    for i in range(1, n - 1):
+        if xf[i] > thr and xf[i] > xf[i - 1] and xf[i] > xf[i + 1] and i - last >= min_dist:
+            peaks.append(i)
+            last = i
+    spacing = float(np.std(np.diff(np.asarray(freqs)[peaks]))) if len(peaks) >= 3 else 0.0   # :214-219
+    return {"noise_floor_db": noise_floor_db, "snr_db": snr_db, "bandwidth_hz_3db": obw(3),
+            "bandwidth_hz_10db": obw(10), "bandwidth_hz_20db": obw(20), "spectral_flatness": sfm,
+            "spectral_kurtosis": kurt, "adaptive_threshold_db": float(thr), "peak_idx": np.array(peaks, dtype=np.int64),
+            "peak_count": len(peaks), "peak_spacing_std_hz": spacing}
+
+
 class Waterfall:
     """app/dashboard/callbacks.py:19,176,182: ``deque(maxlen=100)``, ``append(power_db)``,
     ``np.array(deque)`` — rows oldest first; y axis = range(len) (:186)."""

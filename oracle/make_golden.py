@@ -148,6 +148,31 @@ def main():
     np.savez_compressed(os.path.join(OUT, "ref_welch.npz"), iq=x, fs=np.array([fs]), pxx=pxx, freqs=f,
                         pxx_noverlap512=pxx_ov)
 
+    # ---- classifier feature helpers (app/processing/classifier.py:163-219), run as the reference
+    # calls them at :45-58, on rows the reference itself produced above plus an OFDM-like comb ----
+    from app.processing import classifier as C
+    g4 = np.load(os.path.join(OUT, "ref_n4096.npz"))
+    rows = {k: g4[f"{k}/power_db_c64"] for k in ("pluto12_noise", "gauss_noise", "tone_offbin_k100p37",
+                                                 "two_tones_60db", "tone_plus_pluto_noise", "impulse_n1")}
+    comb = synth.synth_iq(21, 0, 1, 4096)[0] * np.float32(0.02)
+    for kk in range(-1500, 1501, 100):
+        comb = comb + synth.tone(4096, kk, amplitude=30.0)
+    rows["comb_31_tones"] = run_reference(S, [comb.astype(np.complex64)], 20_000_000, 2_400_000_000)[0]["power_db"]
+    freqs = run_reference(S, [comb.astype(np.complex64)], 20_000_000, 2_400_000_000)[0]["freqs"]
+    store = {"names": np.array(sorted(rows)), "freqs": freqs}
+    for k in sorted(rows):
+        p = rows[k]
+        nf = C._estimate_noise_floor(p)
+        snr = float(np.max(p) - nf)
+        thr = max(nf + 5.0, np.max(p) - 0.9 * snr + 5.0)
+        pk = C._find_peaks(p, threshold_db=thr, min_distance_bins=max(3, len(p) // 300))
+        store[f"{k}/power_db"] = p
+        store[f"{k}/scalars"] = np.array([nf, snr, C._occupied_bandwidth(freqs, p, 3), C._occupied_bandwidth(freqs, p, 10),
+                                          C._occupied_bandwidth(freqs, p, 20), C._spectral_flatness(p),
+                                          C._spectral_kurtosis(p), float(thr), C._peak_spacing_std(freqs, pk)], dtype=np.float64)
+        store[f"{k}/peak_idx"] = np.array(pk, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "ref_classifier_features.npz"), **store)
+
     # ---- waterfall: the reference's deque semantics (callbacks.py:19,176,182) ----
     # The callback module needs dash/plotly and a live streamer, so the deque lines
     # are exercised directly: 103 appends into deque(maxlen=100) -> rows 3..102.

@@ -67,6 +67,8 @@ SYMBOLS = [
     ("sdrk_exec_device_timed", c_int,
      [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float)]),
     ("sdrk_synth_fill", c_int, [c_int, c_uint32, c_uint64, c_size_t, c_int, c_void_p, c_void_p]),
+    ("sdrk_row_stats", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p]),
+    ("sdrk_row_peaks", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("sdrk_waterfall_create", c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     ("sdrk_waterfall_destroy", c_int, [c_void_p]),
     ("sdrk_waterfall_append_rows", c_int, [c_void_p, c_void_p, c_size_t]),

@@ -453,6 +453,66 @@ int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_fr
     return SDRK_OK;
 }
 
+/* ---- per-row reductions ---------------------------------------------------- */
+
+namespace {
+struct DevBuf {  // scoped device allocation
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+int sdrk_row_stats(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
+                   double* out) {
+    if (n_rows == 0) return SDRK_OK;
+    if (!rows || !out) return fail(SDRK_ERR_INVALID, "rows or out is NULL");
+    if (nfft < 1) return fail(SDRK_ERR_INVALID, "nfft must be >= 1");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf drows, dout;
+    const float* d_rows = rows;
+    if (!rows_on_device) {
+        HIP_TRY(hipMalloc(&drows.p, n_rows * (size_t)nfft * sizeof(float)));
+        HIP_TRY(hipMemcpy(drows.p, rows, n_rows * (size_t)nfft * sizeof(float), hipMemcpyHostToDevice));
+        d_rows = static_cast<const float*>(drows.p);
+    }
+    HIP_TRY(hipMalloc(&dout.p, n_rows * 16 * sizeof(double)));
+    hipError_t e = sdrk::launch_row_stats(d_rows, n_rows, nfft, rank, static_cast<double*>(dout.p), nullptr);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "row_stats launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(out, dout.p, n_rows * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    return SDRK_OK;
+}
+
+int sdrk_row_peaks(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft,
+                   const double* thresholds, int min_distance, int max_peaks, int32_t* out_idx,
+                   int32_t* out_count) {
+    if (n_rows == 0) return SDRK_OK;
+    if (!rows || !thresholds || !out_idx || !out_count) return fail(SDRK_ERR_INVALID, "NULL pointer");
+    if (nfft < 1 || max_peaks < 1 || min_distance < 1)
+        return fail(SDRK_ERR_INVALID, "nfft, max_peaks and min_distance must be >= 1");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf drows, dthr, didx, dcnt;
+    const float* d_rows = rows;
+    if (!rows_on_device) {
+        HIP_TRY(hipMalloc(&drows.p, n_rows * (size_t)nfft * sizeof(float)));
+        HIP_TRY(hipMemcpy(drows.p, rows, n_rows * (size_t)nfft * sizeof(float), hipMemcpyHostToDevice));
+        d_rows = static_cast<const float*>(drows.p);
+    }
+    HIP_TRY(hipMalloc(&dthr.p, n_rows * sizeof(double)));
+    HIP_TRY(hipMemcpy(dthr.p, thresholds, n_rows * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&didx.p, n_rows * (size_t)max_peaks * sizeof(int)));
+    HIP_TRY(hipMalloc(&dcnt.p, n_rows * sizeof(int)));
+    hipError_t e = sdrk::launch_row_peaks(d_rows, n_rows, nfft, static_cast<const double*>(dthr.p), min_distance,
+                                          max_peaks, static_cast<int*>(didx.p), static_cast<int*>(dcnt.p), nullptr);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "row_peaks launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(out_idx, didx.p, n_rows * (size_t)max_peaks * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_count, dcnt.p, n_rows * sizeof(int), hipMemcpyDeviceToHost));
+    return SDRK_OK;
+}
+
 /* ---- waterfall ring ------------------------------------------------------ */
 
 int sdrk_waterfall_create(int device, int nfft, int maxlen, sdrk_waterfall** out) {

@@ -1,0 +1,149 @@
+"""Spectrum-row features computed next to the rows on the GPU.
+
+The reference's first consumer of every ``power_db`` row is its rule-based classifier
+(app/processing/classifier.py:30-161), which starts by measuring the row with a handful
+of O(N) helpers:
+
+    _estimate_noise_floor   :179-181   20th percentile
+    _occupied_bandwidth     :163-170   span of bins within 3 / 10 / 20 dB of the peak
+    _spectral_flatness      :183-189   geometric / arithmetic mean of linear power
+    _spectral_kurtosis      :191-198   fourth standardised moment of the dB values
+    _find_peaks             :200-212   strict local maxima above a threshold, greedy spacing
+    _peak_spacing_std       :214-219
+
+``row_features`` returns those measurements from two device kernels
+(csrc/row_features.hip) — reductions, an exact radix select for the percentile's order
+statistics and the peak scan — plus a few scalar combinations done here with the same
+dtype rules numpy applies in the reference (float32 percentile interpolation, NEP-50
+scalar promotion in the adaptive threshold).  The label ladder (:69-122) and the 12-frame
+smoothing (:125-139) are application logic and are not reproduced.
+
+``frame_features`` transforms IQ frames and reduces the rows without the rows ever leaving
+the device.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import c_void_p, check, lib
+
+_STATS = 16
+
+
+def _percentile_from_order_stats(n: int, q: float, lo_val: np.ndarray, hi_val: np.ndarray):
+    """numpy.percentile(float32 row, q) given sorted[lo], sorted[lo+1]: numpy forms the
+    quantile, the virtual index and the interpolation weight in the array's dtype."""
+    q32 = np.float32(q) / np.float32(100)
+    vi = np.float32(n - 1) * q32
+    lo = np.floor(vi)
+    gamma = np.float32(vi - lo)
+    a, b = lo_val.astype(np.float32), hi_val.astype(np.float32)
+    diff = b - a
+    out = a + diff * gamma
+    if gamma >= np.float32(0.5):
+        out = b - diff * (np.float32(1) - gamma)
+    return out.astype(np.float32)
+
+
+def percentile_rank(n: int, q: float) -> int:
+    return int(np.floor(np.float32(n - 1) * (np.float32(q) / np.float32(100))))
+
+
+def _features_from_device(ptr, on_device: bool, n_rows: int, nfft: int, freqs, device: int,
+                          percentile: float, max_peaks: int) -> List[dict]:
+    stats = np.empty((n_rows, _STATS), dtype=np.float64)
+    rank = percentile_rank(nfft, percentile)
+    check(lib().sdrk_row_stats(device, ptr, int(on_device), ctypes.c_size_t(n_rows), nfft, rank,
+                               stats.ctypes.data_as(c_void_p)))
+    mx32 = stats[:, 0].astype(np.float32)
+    nf32 = _percentile_from_order_stats(nfft, percentile, stats[:, 1], stats[:, 2])
+    thr = np.empty(n_rows, dtype=np.float64)
+    snr = np.empty(n_rows, dtype=np.float64)
+    for r in range(n_rows):
+        noise_floor_db = float(nf32[r])                                   # :181
+        snr_db = float(mx32[r] - np.float32(noise_floor_db))               # :46 (float32 - weak python float)
+        second = (mx32[r] - np.float32(0.9 * snr_db)) + np.float32(5.0)    # :55, float32 under NEP 50
+        first = noise_floor_db + 5.0
+        # python max(first, second): `second > first` is evaluated in float32 (first is a weak python float)
+        thr[r] = float(second) if second > np.float32(first) else first
+        snr[r] = snr_db
+    min_distance = max(3, nfft // 300)                                     # :56
+    idx = np.empty((n_rows, max_peaks), dtype=np.int32)
+    cnt = np.empty(n_rows, dtype=np.int32)
+    check(lib().sdrk_row_peaks(device, ptr, int(on_device), ctypes.c_size_t(n_rows), nfft,
+                               thr.ctypes.data_as(c_void_p), min_distance, max_peaks,
+                               idx.ctypes.data_as(c_void_p), cnt.ctypes.data_as(c_void_p)))
+    f = None if freqs is None else np.asarray(freqs, dtype=np.float64)
+    out = []
+    for r in range(n_rows):
+        s = stats[r]
+        peaks = idx[r, : min(int(cnt[r]), max_peaks)].copy()
+        sigma = float(np.sqrt(s[4]))
+        d = {
+            "max_db": float(mx32[r]),
+            "argmax": int(s[14]),
+            "noise_floor_db": float(nf32[r]),
+            "snr_db": float(snr[r]),
+            "spectral_flatness": float(np.clip(np.exp(s[6]) / s[7], 0.0, 1.0)),      # :186-189
+            "spectral_kurtosis": 0.0 if sigma < 1e-9 else float(s[5] / (s[4] * s[4])),  # :195-198
+            "adaptive_threshold_db": float(thr[r]),
+            "peak_idx": peaks,
+            "peak_count": int(cnt[r]),
+            "occupied_bins_3db": (int(s[8]), int(s[9])),
+            "occupied_bins_10db": (int(s[10]), int(s[11])),
+            "occupied_bins_20db": (int(s[12]), int(s[13])),
+        }
+        if f is not None:
+            d["bandwidth_hz_3db"] = float(f[int(s[9])] - f[int(s[8])])               # :169-170
+            d["bandwidth_hz_10db"] = float(f[int(s[11])] - f[int(s[10])])
+            d["bandwidth_hz_20db"] = float(f[int(s[13])] - f[int(s[12])])
+            d["peak_spacing_std_hz"] = float(np.std(np.diff(f[peaks]))) if len(peaks) >= 3 else 0.0  # :214-219
+            d["peak_density"] = d["peak_count"] / max(nfft, 1)
+        out.append(d)
+    return out
+
+
+def row_features(power_db, freqs=None, *, device: int = 0, percentile: float = 20.0, max_peaks: int = 4096):
+    """Features of one ``power_db`` row ``(N,)`` -> dict, or of rows ``(R, N)`` -> list of dicts."""
+    _ffi.require_device(device)
+    rows = np.ascontiguousarray(np.asarray(power_db, dtype=np.float32))
+    one = rows.ndim == 1
+    if one:
+        rows = rows.reshape(1, -1)
+    if rows.ndim != 2 or rows.shape[1] < 1:
+        raise ValueError(f"expected (N,) or (R, N) rows, got {rows.shape}")
+    res = _features_from_device(rows.ctypes.data_as(c_void_p), False, rows.shape[0], rows.shape[1], freqs, device,
+                                percentile, max_peaks)
+    return res[0] if one else res
+
+
+def frame_features(samples, sample_rate: float, center_freq: float, *, window=None, eps: float = 1e-12,
+                   device: int = 0, percentile: float = 20.0, max_peaks: int = 4096):
+    """IQ frame(s) -> features, rows staying in HBM: the transform (streamer.py:119,121) writes its
+    rows to a device buffer and only the per-row scalars and peak indices come back."""
+    from .spectrum import _as_c64, _cached_plan, freq_axis
+    x = _as_c64(samples)
+    one = x.ndim == 1
+    if one:
+        x = x.reshape(1, -1)
+    n_rows, nfft = x.shape
+    plan = _cached_plan(nfft, window, eps, True, device)
+    freqs = freq_axis(nfft, sample_rate, center_freq)
+    d_in, d_out = c_void_p(), c_void_p()
+    check(lib().sdrk_dev_alloc(device, x.nbytes, ctypes.byref(d_in)))
+    try:
+        check(lib().sdrk_dev_alloc(device, n_rows * nfft * 4, ctypes.byref(d_out)))
+        try:
+            check(lib().sdrk_memcpy_h2d(device, d_in, x.ctypes.data_as(c_void_p), x.nbytes))
+            plan.exec_device(d_in.value, n_rows, d_out.value)
+            plan.sync()
+            res = _features_from_device(d_out, True, n_rows, nfft, freqs, device, percentile, max_peaks)
+        finally:
+            lib().sdrk_dev_free(device, d_out)
+    finally:
+        lib().sdrk_dev_free(device, d_in)
+    return res[0] if one else res

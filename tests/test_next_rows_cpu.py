@@ -133,3 +133,29 @@ def test_sigmf_source_cuts_and_loops(tmp_path):
         src2.rx()
     with pytest.raises(EOFError):
         src2.rx()
+
+
+def test_oracle_row_features_match_reference_classifier_helpers(golden):
+    """f1: the oracle's restatement of app/processing/classifier.py:163-219 against values the
+    reference's own helpers returned (oracle/make_golden.py)."""
+    g = golden["ref_classifier_features"]
+    for k in (str(n) for n in g["names"]):
+        f = cpu_ref.row_features(g["freqs"], g[f"{k}/power_db"])
+        got = np.array([f["noise_floor_db"], f["snr_db"], f["bandwidth_hz_3db"], f["bandwidth_hz_10db"],
+                        f["bandwidth_hz_20db"], f["spectral_flatness"], f["spectral_kurtosis"],
+                        f["adaptive_threshold_db"], f["peak_spacing_std_hz"]])
+        assert np.array_equal(got, g[f"{k}/scalars"]), k
+        assert np.array_equal(f["peak_idx"], g[f"{k}/peak_idx"]), k
+
+
+def test_percentile_rank_and_interpolation_mirror_numpy():
+    from sdr_iq_visualizer_amd import features
+    rng = np.random.default_rng(9)
+    for n in (5, 64, 300, 1000, 4096, 65536):
+        x = rng.standard_normal(n).astype(np.float32)
+        s = np.sort(x)
+        for q in (20.0, 50.0, 95.0, 33.3):
+            r = features.percentile_rank(n, q)
+            hi = min(r + 1, n - 1)
+            got = features._percentile_from_order_stats(n, q, np.array([s[r]]), np.array([s[hi]]))[0]
+            assert got == np.percentile(x, q), (n, q)

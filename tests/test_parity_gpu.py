@@ -366,3 +366,60 @@ def test_streamer_shim_on_gpu(pkg):
         wf.append(d["power_db"])
         n += 1
     assert len(wf) == min(n, 100) and wf.as_array().shape == (len(wf), 4096)
+
+
+def _check_features(got, g, k, freqs):
+    s = g[f"{k}/scalars"]
+    assert got["noise_floor_db"] == s[0] and got["snr_db"] == s[1], k            # exact: order statistics
+    assert (got["bandwidth_hz_3db"], got["bandwidth_hz_10db"], got["bandwidth_hz_20db"]) == (s[2], s[3], s[4]), k
+    assert abs(got["spectral_flatness"] - s[5]) <= 1e-9 * max(1.0, abs(s[5])), k  # float64 sums, other order
+    assert abs(got["spectral_kurtosis"] - s[6]) <= 1e-9 * max(1.0, abs(s[6])), k
+    assert got["adaptive_threshold_db"] == s[7], k
+    assert np.array_equal(got["peak_idx"], g[f"{k}/peak_idx"]) and got["peak_count"] == len(g[f"{k}/peak_idx"]), k
+    assert got["peak_spacing_std_hz"] == s[8], k
+    assert got["argmax"] == int(np.argmax(g[f"{k}/power_db"]))
+
+
+def test_row_features_vs_reference_classifier_helpers(pkg, golden):
+    """f1: device reductions vs what the reference's helpers returned (classifier.py:163-219)."""
+    from sdr_iq_visualizer_amd import features
+    g = golden["ref_classifier_features"]
+    names = [str(n) for n in g["names"]]
+    for k in names:
+        _check_features(features.row_features(g[f"{k}/power_db"], g["freqs"]), g, k, g["freqs"])
+    batch = features.row_features(np.stack([g[f"{k}/power_db"] for k in names]), g["freqs"])
+    for k, got in zip(names, batch):
+        _check_features(got, g, k, g["freqs"])
+    capped = features.row_features(g["pluto12_noise/power_db"], g["freqs"], max_peaks=10)
+    assert capped["peak_count"] == len(g["pluto12_noise/peak_idx"]) and len(capped["peak_idx"]) == 10
+    assert np.array_equal(capped["peak_idx"], g["pluto12_noise/peak_idx"][:10])
+
+
+def test_row_features_other_sizes_vs_oracle(pkg):
+    from sdr_iq_visualizer_amd import features
+    rng = np.random.default_rng(17)
+    for n in (64, 1000, 4096, 65536):
+        x = rand_c64(rng, n, scale=30.0) + 500 * np.exp(2j * np.pi * 0.1 * np.arange(n)).astype(np.complex64)
+        row = cpu_ref.spectrum_db(x.astype(np.complex64)) if n & (n - 1) == 0 else \
+            (20 * np.log10(np.abs(np.fft.fftshift(np.fft.fft(x))) + 1e-12)).astype(np.float32)
+        freqs = cpu_ref.freq_axis(n, 2e6, 1e9)
+        got, ref = features.row_features(row, freqs), cpu_ref.row_features(freqs, row)
+        for key in ("noise_floor_db", "snr_db", "bandwidth_hz_3db", "bandwidth_hz_10db", "bandwidth_hz_20db",
+                    "adaptive_threshold_db", "peak_spacing_std_hz"):
+            assert got[key] == ref[key], (n, key)
+        assert np.array_equal(got["peak_idx"], ref["peak_idx"])
+        assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= 1e-9
+        assert abs(got["spectral_kurtosis"] - ref["spectral_kurtosis"]) <= 1e-9 * ref["spectral_kurtosis"]
+
+
+def test_frame_features_rows_stay_on_device(pkg):
+    from sdr_iq_visualizer_amd import features, synth
+    x = (synth.synth_iq(3, 0, 4, 4096) * np.float32(0.05) + synth.tone(4096, 700.0, 300.0)).astype(np.complex64)
+    got = features.frame_features(x, 1_000_000, 2_400_000_000)
+    rows = pkg.spectrum_db(x)                                       # same kernel -> same float32 rows
+    freqs = cpu_ref.freq_axis(4096, 1_000_000, 2_400_000_000)
+    for r in range(4):
+        ref = cpu_ref.row_features(freqs, rows[r])
+        assert got[r]["noise_floor_db"] == ref["noise_floor_db"] and got[r]["snr_db"] == ref["snr_db"]
+        assert np.array_equal(got[r]["peak_idx"], ref["peak_idx"]) and got[r]["argmax"] == 2048 + 700
+        assert got[r]["bandwidth_hz_20db"] == ref["bandwidth_hz_20db"]
