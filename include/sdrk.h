@@ -184,6 +184,13 @@ int sdrk_waterfall_rows(const sdrk_waterfall* wf);
  * number written is returned through n_rows.  If fewer than rows() fit, the
  * NEWEST max_rows are returned (still oldest-of-those first). */
 int sdrk_waterfall_read(sdrk_waterfall* wf, float* out, size_t max_rows, size_t* n_rows);
+/* Decimated read-out for display: like sdrk_waterfall_read, but every run of `factor`
+ * consecutive bins is reduced on the device to one value — mode 0 = max (peak hold),
+ * mode 1 = mean of the dB values — so `out` holds rows of nfft/factor float32.  factor
+ * must divide nfft.  (Build-side extension: the reference plots full rows,
+ * dashboard/callbacks.py:182-190, which is unusable at nfft = 2^20.) */
+int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
+                                  size_t* n_rows);
 int sdrk_waterfall_clear(sdrk_waterfall* wf);
 
 #ifdef __cplusplus

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("sdrk_waterfall_append_iq_device", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t]),
     ("sdrk_waterfall_rows", c_int, [c_void_p]),
     ("sdrk_waterfall_read", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]),
+    ("sdrk_waterfall_read_decimated", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, POINTER(c_size_t)]),
     ("sdrk_waterfall_clear", c_int, [c_void_p]),
 ]
 

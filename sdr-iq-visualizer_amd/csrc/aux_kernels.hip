@@ -71,6 +71,45 @@ __global__ __launch_bounds__(256) void power_mean_kernel(const float2* __restric
     out[k] = acc * scale;
 }
 
+// Display decimation of waterfall rows: out[r][b] = max (mode 0) or mean (mode 1) of the
+// `factor` consecutive dB values in[r][b*factor .. (b+1)*factor).  One wave per output bin
+// group: lanes stride the factor-long run (coalesced), then a wave reduction.  No reference
+// counterpart (the reference draws full rows, app/dashboard/callbacks.py:182-190); it makes
+// N = 2^20 rows drawable.  `row_of` maps output row r to its ring slot.
+__global__ __launch_bounds__(256) void decimate_rows_kernel(const float* __restrict__ ring, int nfft, int maxlen,
+                                                            int start_slot, int n_rows, int factor, int mode,
+                                                            float* __restrict__ out) {
+    const int bins = nfft / factor;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t total = (size_t)n_rows * bins;
+    for (size_t item = (size_t)blockIdx.x * 4 + wave; item < total; item += (size_t)gridDim.x * 4) {
+        const int r = (int)(item / bins), b = (int)(item - (size_t)r * bins);
+        const float* __restrict__ src = ring + (size_t)((start_slot + r) % maxlen) * nfft + (size_t)b * factor;
+        float acc = mode == 0 ? -INFINITY : 0.0f;
+        for (int i = lane; i < factor; i += 64) {
+            const float v = src[i];
+            acc = mode == 0 ? fmaxf(acc, v) : acc + v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_down(acc, o, 64);
+            acc = mode == 0 ? fmaxf(acc, other) : acc + other;
+        }
+        if (lane == 0) out[item] = mode == 0 ? acc : acc / (float)factor;
+    }
+}
+
+hipError_t launch_decimate_rows(const float* d_ring, int nfft, int maxlen, int start_slot, int n_rows, int factor,
+                                int mode, float* d_out, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    size_t total = (size_t)n_rows * (nfft / factor);
+    size_t blocks = (total + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(decimate_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_ring, nfft, maxlen,
+                       start_slot, n_rows, factor, mode, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,
                              hipStream_t stream) {
     hipLaunchKernelGGL(power_mean_kernel, dim3((nfft + 255) / 256), dim3(256), 0, stream,

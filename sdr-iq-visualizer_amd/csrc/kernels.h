@@ -60,6 +60,8 @@ hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frame
 hipError_t launch_row_stats(const float* d_rows, size_t n_rows, int nfft, int rank, double* d_out, hipStream_t s);
 hipError_t launch_row_peaks(const float* d_rows, size_t n_rows, int nfft, const double* d_thr, int min_distance,
                             int max_peaks, int* d_idx, int* d_count, hipStream_t s);
+hipError_t launch_decimate_rows(const float* d_ring, int nfft, int maxlen, int start_slot, int n_rows, int factor,
+                                int mode, float* d_out, hipStream_t stream);
 hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,
                              hipStream_t stream);
 

@@ -653,4 +653,28 @@ int sdrk_waterfall_read(sdrk_waterfall* wf, float* out, size_t max_rows, size_t*
     return SDRK_OK;
 }
 
+int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
+                                  size_t* n_rows) {
+    if (!wf || !n_rows) return fail(SDRK_ERR_INVALID, "waterfall or n_rows is NULL");
+    *n_rows = 0;
+    if (factor < 1 || wf->nfft % factor != 0) return fail(SDRK_ERR_INVALID, "factor %d must divide nfft %d", factor, wf->nfft);
+    if (mode != 0 && mode != 1) return fail(SDRK_ERR_INVALID, "mode must be 0 (max) or 1 (mean)");
+    size_t rows = wf->count < max_rows ? wf->count : max_rows;
+    if (rows == 0) return SDRK_OK;
+    if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
+    HIP_TRY(hipSetDevice(wf->device));
+    const size_t L = (size_t)wf->maxlen;
+    const size_t start = (wf->head + L - rows % L) % L;
+    const size_t bins = (size_t)(wf->nfft / factor);
+    DevBuf tmp;
+    HIP_TRY(hipMalloc(&tmp.p, rows * bins * sizeof(float)));
+    hipError_t e = sdrk::launch_decimate_rows(wf->d_ring, wf->nfft, wf->maxlen, (int)start, (int)rows, factor, mode,
+                                              static_cast<float*>(tmp.p), wf->stream);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "decimate launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(out, tmp.p, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->stream));
+    HIP_TRY(hipStreamSynchronize(wf->stream));
+    *n_rows = rows;
+    return SDRK_OK;
+}
+
 }  // extern "C"

@@ -117,9 +117,23 @@ class WaterfallBuffer:
             check(lib().sdrk_waterfall_append_iq(self._h(), self._plan.handle, x.ctypes.data_as(c_void_p),
                                                  c_size_t(n_frames), c_size_t(stride)))
 
-    def as_array(self, max_rows: Optional[int] = None) -> np.ndarray:
+    def as_array(self, max_rows: Optional[int] = None, *, decimate: int = 1, mode: str = "max") -> np.ndarray:
         """``np.array(deque)``: float32 ``(rows, nfft)``, oldest row at index 0.  With
-        ``max_rows`` only the newest ``max_rows`` rows are returned."""
+        ``max_rows`` only the newest ``max_rows`` rows are returned.  ``decimate=f`` reduces every
+        run of ``f`` bins on the device (``mode`` "max" = peak hold, "mean" = mean of dB values)
+        and returns ``(rows, nfft // f)`` — for drawing long rows (N = 2^20) in a heatmap."""
+        if decimate != 1:
+            if mode not in ("max", "mean"):
+                raise ValueError("mode must be 'max' or 'mean'")
+            if decimate < 1 or self.nfft % decimate:
+                raise ValueError(f"decimate={decimate} must divide nfft={self.nfft}")
+            with self._lock:
+                rows = len(self) if max_rows is None else min(len(self), int(max_rows))
+                out = np.empty((rows, self.nfft // decimate), dtype=np.float32)
+                got = c_size_t(0)
+                check(lib().sdrk_waterfall_read_decimated(self._h(), out.ctypes.data_as(c_void_p), c_size_t(rows),
+                                                          int(decimate), 0 if mode == "max" else 1, byref(got)))
+                return out[: got.value]
         with self._lock:
             rows = len(self)
             if max_rows is not None:

@@ -423,3 +423,26 @@ def test_frame_features_rows_stay_on_device(pkg):
         assert got[r]["noise_floor_db"] == ref["noise_floor_db"] and got[r]["snr_db"] == ref["snr_db"]
         assert np.array_equal(got[r]["peak_idx"], ref["peak_idx"]) and got[r]["argmax"] == 2048 + 700
         assert got[r]["bandwidth_hz_20db"] == ref["bandwidth_hz_20db"]
+
+
+def test_waterfall_decimated_readout(pkg):
+    """f4 (build-side extension): device max-hold / mean decimation of ring rows before D2H."""
+    rng = np.random.default_rng(31)
+    wf = pkg.WaterfallBuffer(4096, maxlen=6)
+    rows = rng.standard_normal((9, 4096)).astype(np.float32) * 10
+    wf.append(rows)                                                # wraps: rows 3..8 remain
+    kept = rows[3:]
+    for f in (1, 2, 16, 64, 512, 4096):
+        got = wf.as_array(decimate=f, mode="max")
+        assert got.shape == (6, 4096 // f)
+        assert np.array_equal(got, kept.reshape(6, 4096 // f, f).max(-1))
+        mean = wf.as_array(decimate=f, mode="mean")
+        assert np.allclose(mean, kept.reshape(6, 4096 // f, f).mean(-1, dtype=np.float64), atol=1e-4)
+    assert np.array_equal(wf.as_array(max_rows=2, decimate=8), kept[-2:].reshape(2, 512, 8).max(-1))
+    with pytest.raises(ValueError):
+        wf.as_array(decimate=3)
+    big = pkg.WaterfallBuffer(1 << 20, maxlen=3)                   # config 5 row length -> 4096 px
+    x = rand_c64(rng, 2, 1 << 20, scale=2.0)
+    big.append(x)
+    full = big.as_array()
+    assert np.array_equal(big.as_array(decimate=256), full.reshape(2, 4096, 256).max(-1))
