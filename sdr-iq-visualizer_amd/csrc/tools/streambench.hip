@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <utility>
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -37,6 +38,29 @@ __global__ __launch_bounds__(256) void stream_k(const v4f* __restrict__ in, v4f*
         }
     }
     if (!DO_WRITE && acc.x == 12345.678f) out[0] = acc;
+}
+
+// TDMA experiment: the whole chip reads during [0,TR) and writes during [TR,TR+TW) of a
+// period measured on the shared 100 MHz s_memrealtime clock, so that HBM sees long
+// read-only and write-only bursts instead of a fine-grained mix.
+__global__ __launch_bounds__(256) void tdma_k(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n_frames,
+                                              unsigned TR, unsigned TW) {
+    const unsigned period = TR + TW;
+    for (size_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const v4f* x = in + f * 2048;
+        v4f* o = out + f * 1024;
+        v4f v[8];
+        while ((unsigned)(__builtin_amdgcn_s_memrealtime() % period) >= TR) __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(&x[threadIdx.x + 256 * j]);
+        v4f r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = v[2 * j] + v[2 * j + 1];   // forces the loads to complete
+        asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+        while ((unsigned)(__builtin_amdgcn_s_memrealtime() % period) < TR) __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(r[j], &o[threadIdx.x + 256 * j]);
+    }
 }
 
 // classic copy: n float4 in -> n float4 out, grid-stride
@@ -84,6 +108,14 @@ int main(int argc, char** argv) {
         printf("bpc %d  read-only nt          %8.3f ms %7.1f GB/s\n", bpc, t, ro / t / 1e6);
         t = time_it(reps, s, [&] { hipLaunchKernelGGL((stream_k<1, 0, 0, 1>), dim3(g), dim3(256), 0, s, in, out, nf); });
         printf("bpc %d  write-only nt         %8.3f ms %7.1f GB/s\n", bpc, t, wo / t / 1e6);
+    }
+    for (int bpc : {3, 4, 6, 8}) {
+        unsigned g = cus * bpc;
+        double rw = 12.0 * nf * 4096;
+        for (auto tr_tw : {std::pair<unsigned, unsigned>{175, 110}, {350, 220}, {700, 440}, {1400, 880}, {350, 350}, {240, 240}}) {
+            float t = time_it(reps, s, [&] { hipLaunchKernelGGL(tdma_k, dim3(g), dim3(256), 0, s, in, out, nf, tr_tw.first, tr_tw.second); });
+            printf("bpc %d  TDMA TR=%4u TW=%4u (x10 ns)   %8.3f ms %7.1f GB/s\n", bpc, tr_tw.first, tr_tw.second, t, rw / t / 1e6);
+        }
     }
     size_t n4 = nf * 2048;  // float4 count of the input
     for (int bpc : {4, 8, 16}) {
