@@ -1,0 +1,274 @@
+// fft_fused64k.hip — N = 65536 (BASELINE.json config 3: the waterfall STFT) in ONE
+// persistent launch whose intermediate never leaves the XCD it was produced on.
+//
+// Same arithmetic as the two tiled passes of fft_tiled.hip (K1 col256: DFT-256 down
+// 16-wide column tiles, times W_N^(m k3); K3 row256: DFT-256 along 16 adjacent rows,
+// fftshift, log epilogue) — bit-identical results — but the 512 KiB complex64
+// intermediate of a frame lives in a small ring inside ONE XCD's 4 MiB L2 instead of
+// crossing the fabric twice (16 of the 28 B/sample the two-launch form moves).
+//
+// MI355X has 8 XCDs, each with its own L2; HIP promises nothing about which XCD a
+// workgroup runs on, so nothing here assumes a placement: every workgroup READS its
+// XCC id (s_getreg HW_REG_XCC_ID) and joins that XCD's task queue.
+//
+//   queue[x]        tasks of XCD x in order: slot s = t/32, sub = t%32
+//                   sub <  16 : K1 tile `sub`    of the frame in slot s     -> ring[x][s % S]
+//                   sub >= 16 : K3 tile `sub-16` of the frame in slot s - 1 <- ring[x][(s-1) % S]
+//   frame_of[x][s]  the workgroup that draws (s, 0) takes the next frame number from one
+//                   global counter and publishes it (END once the frames run out)
+//   done1/done3     per-slot completion counts of the 16 K1 / 16 K3 tiles: K3 waits for
+//                   done1[s-1] == 16; K1 waits for done3[s-S] == 16 before reusing a ring slot
+//
+// Visibility inside one XCD: a producer's plain stores are complete in the shared L2
+// once its `s_waitcnt vmcnt(0)` returns; it then bumps done1 with an agent-scope atomic.
+// The consumer polls done1 (agent-scope load), then reads the ring with sc1 loads, which
+// bypass its CU's L1 and are served by that same L2.  No L2 write-back is needed because
+// producer and consumer were verified, by XCC id, to share the L2.
+// Waits only ever point at tasks drawn earlier from the same queue, so there is no
+// cycle; every spin is bounded and a timeout raises an error flag instead of hanging.
+#include "fft4096_core.h"
+
+namespace sdrk {
+
+constexpr int FU_THREADS = 256;
+constexpr int FU_N = 65536;
+constexpr int FU_RING_SLOTS = 6;             // 6 x 512 KiB = 3 MiB of each XCD's 4 MiB L2
+constexpr unsigned FU_END = 0xFFFFFFFFu;
+constexpr unsigned FU_POISON = 0xFFFFFFFEu;  // returned by wg_wait after a timeout / error: caller leaves
+constexpr unsigned FU_SPIN_LIMIT = 1u << 18; // polls (~1-2 us each under load): give up after a fraction of a second
+constexpr int FU_MAX_XCD = 16;
+
+// control block layout (unsigned words), zeroed before every launch
+//   [0] next frame   [1] error flag   [32 + x*XS ...] per XCD: [0] queue head, then at +32:
+//   frame_of[max_slots], done1[max_slots], done3[max_slots]
+__host__ __device__ inline size_t fu_xcd_stride(unsigned max_slots) { return 32 + 3 * (size_t)((max_slots + 31) & ~31u); }
+__host__ inline size_t fused64k_ctrl_words(unsigned max_slots) { return 32 + FU_MAX_XCD * fu_xcd_stride(max_slots); }
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Thread 0 spins until *p >= want (or, for want == 0, until *p != 0); everyone gets the value.
+__device__ __forceinline__ unsigned wg_wait(const unsigned* p, unsigned want, unsigned* err, unsigned* sh,
+                                            unsigned spin_limit = FU_SPIN_LIMIT) {
+    if (threadIdx.x == 0) {
+        unsigned v = ld_agent(p), spins = 0;
+        while (want ? v < want : v == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > spin_limit || ld_agent(err)) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = FU_POISON;
+                break;
+            }
+            v = ld_agent(p);
+        }
+        *sh = v;
+    }
+    __syncthreads();
+    const unsigned v = *sh;
+    __syncthreads();
+    return v;
+}
+
+template <bool HAS_WINDOW, int EPILOGUE>
+__global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
+    const float2* __restrict__ iq, size_t frame_stride, void* __restrict__ out_raw, unsigned n_frames,
+    const float* __restrict__ window, const float2* __restrict__ tw4096, const float2* __restrict__ t1,
+    const float2* __restrict__ t2, float2* __restrict__ ring, unsigned* __restrict__ ctrl, unsigned max_slots,
+    float eps, int shift) {
+    __shared__ float2 lds[16 * 272 + 256];
+    __shared__ unsigned sh_u;
+    float2* __restrict__ tw256 = lds + 16 * 272;
+    const int tid = threadIdx.x;
+    const int lo = tid & 15, hi = tid >> 4;
+    tw256[tid] = tw4096[(16 * lo * hi) & 4095];
+
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= FU_MAX_XCD - 1;
+    unsigned* __restrict__ err = ctrl + 1;
+    unsigned* __restrict__ xc = ctrl + 32 + xcc * fu_xcd_stride(max_slots);
+    unsigned* __restrict__ queue = xc;
+    const size_t arr = (max_slots + 31) & ~31u;
+    unsigned* __restrict__ frame_of = xc + 32;
+    unsigned* __restrict__ done1 = frame_of + arr;
+    unsigned* __restrict__ done3 = done1 + arr;
+    float2* __restrict__ my_ring = ring + (size_t)xcc * FU_RING_SLOTS * FU_N;
+    __syncthreads();
+
+    // exchange-1 style addressing for K1 (XOR swizzle), padded layout for K3
+    const int b = hi & 1;
+    const int x1r_even = lo + 256 * hi + 16 * b, x1r_odd = lo + 256 * hi - 16 * b;
+    const int xor_q = shift ? 8 : 0;
+
+    // A workgroup can never legitimately draw more tasks than one XCD's queue holds.
+    const unsigned max_draws = max_slots * 32u;
+    for (unsigned draws = 0;; ++draws) {
+        if (draws > max_draws) {
+            if (tid == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (tid == 0) sh_u = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned t = sh_u;
+        __syncthreads();
+        const unsigned s = t >> 5, sub = t & 31;
+        if (s >= max_slots) {  // cannot happen with the host's sizing; never index past the arrays
+            if (tid == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (sub == 0 && tid == 0) {
+            const unsigned f = __hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(frame_of + s, f < n_frames ? f + 1 : FU_END, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned cur = wg_wait(frame_of + s, 0, err, &sh_u);
+        const unsigned prev = s ? wg_wait(frame_of + s - 1, 0, err, &sh_u) : FU_END;
+        if (cur == FU_POISON || prev == FU_POISON) break;  // (values are workgroup-uniform)
+        if (cur == FU_END && prev == FU_END) break;        // this XCD's work is finished
+
+        if (sub < 16) {
+            // ---------------- K1: column tile `sub` of frame cur-1 -> ring slot s % S ----------------
+            if (cur == FU_END) continue;
+            if (s >= FU_RING_SLOTS && wg_wait(done3 + s - FU_RING_SLOTS, 16, err, &sh_u) == FU_POISON) break;
+            const size_t f = cur - 1;
+            const int m = (int)sub * 16 + lo;
+            const float2* __restrict__ x = iq + f * frame_stride + m;
+            cf v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int off = (hi + 16 * j) * 256;
+                v2f tt = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(x + off));
+                if (HAS_WINDOW) {
+                    const float w = window[off + m];
+                    tt.x *= w;
+                    tt.y *= w;
+                }
+                v[j] = cf{tt.x, tt.y};
+            }
+            radix16(v);
+#pragma unroll
+            for (int p = 1; p < 16; ++p) {
+                float2 w = tw256[16 * p + hi];
+                v[rev16(p)] = cmul(v[rev16(p)], cf{w.x, w.y});
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                lds[((p & 1) ? (tid ^ 16) : tid) + 256 * p] = make_float2(v[rev16(p)].x, v[rev16(p)].y);
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                float2 tt = lds[((a & 1) ? x1r_odd : x1r_even) + 16 * a];
+                v[a] = cf{tt.x, tt.y};
+            }
+            radix16(v);
+            float2* __restrict__ o = my_ring + (size_t)(s % FU_RING_SLOTS) * FU_N + m;
+            const float2 bw = t1[m * 16 + hi];
+            const cf base = cf{bw.x, bw.y};
+            const float4* __restrict__ row = reinterpret_cast<const float4*>(t2 + (size_t)m * 16);
+#pragma unroll
+            for (int q2 = 0; q2 < 8; ++q2) {
+                const float4 w = row[q2];
+                cf z0 = cmul(v[rev16(2 * q2)], cmul(base, cf{w.x, w.y}));
+                cf z1 = cmul(v[rev16(2 * q2 + 1)], cmul(base, cf{w.z, w.w}));
+                o[(hi + 32 * q2) * 256] = make_float2(z0.x, z0.y);
+                o[(hi + 32 * q2 + 16) * 256] = make_float2(z1.x, z1.y);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's ring stores are in the L2
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(done1 + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // ---------------- K3: row tile `sub-16` of frame prev-1 <- ring slot (s-1) % S ----------------
+            if (prev == FU_END) continue;
+            if (wg_wait(done1 + s - 1, 16, err, &sh_u) == FU_POISON) break;
+            const size_t f = prev - 1;
+            const int k3_0 = (int)(sub - 16) * 16;
+            const unsigned long long* __restrict__ in = reinterpret_cast<const unsigned long long*>(
+                my_ring + (size_t)((s - 1) % FU_RING_SLOTS) * FU_N + (size_t)(k3_0 + hi) * 256 + lo);
+            cf v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                // sc1: served by this XCD's L2, never by this CU's (possibly stale) L1
+                const unsigned long long raw = __hip_atomic_load(in + 16 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const v2f tt = __builtin_bit_cast(v2f, raw);
+                v[j] = cf{tt.x, tt.y};
+            }
+            radix16(v);
+#pragma unroll
+            for (int p = 1; p < 16; ++p) {
+                float2 w = tw256[16 * p + lo];
+                v[rev16(p)] = cmul(v[rev16(p)], cf{w.x, w.y});
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                lds[lo + 17 * hi + 272 * p] = make_float2(v[rev16(p)].x, v[rev16(p)].y);
+            __syncthreads();
+            // all of this workgroup's ring reads have returned: the slot may be reused once 16 tiles say so
+            if (tid == 0) __hip_atomic_fetch_add(done3 + s - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                float2 tt = lds[u + 17 * lo + 272 * hi];
+                v[u] = cf{tt.x, tt.y};
+            }
+            radix16(v);
+            if (EPILOGUE == EPI_LOGPSD) {
+                float* __restrict__ o = static_cast<float*>(out_raw) + f * (size_t)FU_N + k3_0 + lo;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int k1 = hi + 16 * (q ^ xor_q);
+                    cf z = v[rev16(q)];
+                    __builtin_nontemporal_store(logpsd_db(z.x, z.y, eps), &o[256 * k1]);
+                }
+            } else {
+                float2* __restrict__ o = static_cast<float2*>(out_raw) + f * (size_t)FU_N + k3_0 + lo;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int k1 = hi + 16 * (q ^ xor_q);
+                    cf z = v[rev16(q)];
+                    o[256 * k1] = make_float2(z.x, z.y);
+                }
+            }
+            __syncthreads();  // LDS is reused by the next task
+        }
+    }
+}
+
+size_t fused64k_ring_bytes() { return (size_t)FU_MAX_XCD * FU_RING_SLOTS * FU_N * sizeof(float2); }
+
+unsigned fused64k_max_slots(size_t n_frames, unsigned grid) { return (unsigned)(n_frames + grid / 16 + 8); }
+
+size_t fused64k_ctrl_words_for(size_t n_frames, int num_cus) {
+    return fused64k_ctrl_words(fused64k_max_slots(n_frames, (unsigned)num_cus * 3));
+}
+
+// d_ctrl must hold fused64k_ctrl_words(max_slots) words; it is zeroed here on the stream.
+hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl, size_t ctrl_capacity_words) {
+    if (a.n_frames == 0) return hipSuccess;
+    if (a.n_frames >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)a.num_cus * 3;
+    const unsigned max_slots = fused64k_max_slots(a.n_frames, grid);
+    const size_t words = fused64k_ctrl_words(max_slots);
+    if (words > ctrl_capacity_words) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_ctrl, 0, words * sizeof(unsigned), a.stream);
+    if (e != hipSuccess) return e;
+    const float2* iq = static_cast<const float2*>(a.d_iq);
+    const float2* tw = static_cast<const float2*>(a.d_twiddle);
+    const float2* t1 = static_cast<const float2*>(a.d_twiddle_big) + 1024 + 4096;
+    const float2* t2 = t1 + 256 * 16;
+    float2* ring = static_cast<float2*>(d_ring);
+#define SDRK_FU(W, E)                                                                                  \
+    hipLaunchKernelGGL((fused64k_kernel<W, E>), dim3(grid), dim3(FU_THREADS), 0, a.stream, iq,          \
+                       a.frame_stride, a.d_out, (unsigned)a.n_frames, a.d_window, tw, t1, t2, ring, d_ctrl, \
+                       max_slots, a.eps, a.shift)
+    if (a.epilogue == EPI_LOGPSD) {
+        if (a.d_window) SDRK_FU(true, EPI_LOGPSD); else SDRK_FU(false, EPI_LOGPSD);
+    } else {
+        if (a.d_window) SDRK_FU(true, EPI_COMPLEX); else SDRK_FU(false, EPI_COMPLEX);
+    }
+#undef SDRK_FU
+    return hipGetLastError();
+}
+
+}  // namespace sdrk

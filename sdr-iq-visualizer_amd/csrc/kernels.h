@@ -57,6 +57,11 @@ hipError_t launch_fft_tiled(const LaunchArgs& a);   // tiled 256 x R x 256 passe
 hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,
                              void* d_iq, hipStream_t stream);
 
+// N = 65536 in one persistent launch, intermediate ring resident in each XCD's L2 (fft_fused64k.hip)
+size_t fused64k_ring_bytes();
+unsigned fused64k_max_slots(size_t n_frames, unsigned grid);
+size_t fused64k_ctrl_words_for(size_t n_frames, int num_cus);
+hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl, size_t ctrl_capacity_words);
 hipError_t launch_row_stats(const float* d_rows, size_t n_rows, int nfft, int rank, double* d_out, hipStream_t s);
 hipError_t launch_row_peaks(const float* d_rows, size_t n_rows, int nfft, const double* d_thr, int min_distance,
                             int max_peaks, int* d_idx, int* d_count, hipStream_t s);

@@ -82,7 +82,15 @@ struct sdrk_plan {
     size_t in_cap = 0;
     void* d_out = nullptr;
     size_t out_cap = 0;
+    // N = 65536 fused path (fft_fused64k.hip)
+    bool fused64k = false;
+    void* d_fused_ring = nullptr;
+    unsigned* d_fused_ctrl = nullptr;
+    size_t fused_ctrl_words = 0;
+    unsigned* h_fused_err = nullptr;   // pinned mailbox: error word of the last launches
+    unsigned fused_launches = 0;
 };
+constexpr unsigned FUSED_MAILBOX = 64;
 
 struct sdrk_waterfall {
     int device = 0;
@@ -119,11 +127,44 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
         e = sdrk::launch_fft4096(a);
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
-    else if (sdrk::fft_tiled_supports(p->nfft))
+    else if (p->fused64k) {
+        // largest launch the control block was sized for; longer batches go through in pieces
+        const size_t piece = 1u << 20;
+        e = hipSuccess;
+        for (size_t f0 = 0; f0 < n_frames && e == hipSuccess; f0 += piece) {
+            sdrk::LaunchArgs b = a;
+            b.n_frames = n_frames - f0 < piece ? n_frames - f0 : piece;
+            b.d_iq = static_cast<const float2*>(d_iq) + f0 * frame_stride;
+            b.d_out = static_cast<char*>(d_out) + f0 * (size_t)p->nfft * (epilogue == sdrk::EPI_LOGPSD ? 4 : 8);
+            const size_t need = sdrk::fused64k_ctrl_words_for(b.n_frames, p->num_cus);
+            if (need > p->fused_ctrl_words) {
+                if (p->d_fused_ctrl) { (void)hipStreamSynchronize(stream); (void)hipFree(p->d_fused_ctrl); p->d_fused_ctrl = nullptr; p->fused_ctrl_words = 0; }
+                e = hipMalloc((void**)&p->d_fused_ctrl, need * sizeof(unsigned));
+                if (e != hipSuccess) break;
+                p->fused_ctrl_words = need;
+            }
+            e = sdrk::launch_fused64k(b, p->d_fused_ring, p->d_fused_ctrl, p->fused_ctrl_words);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(p->h_fused_err + (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl + 1,
+                                   sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+        }
+    } else if (sdrk::fft_tiled_supports(p->nfft))
         e = sdrk::launch_fft_tiled(a);
     else
         e = sdrk::launch_fft_large(a);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return SDRK_OK;
+}
+
+// After a stream sync: did any fused N=65536 launch report an internal wait timeout?
+int fused_check(sdrk_plan* p) {
+    if (!p->fused64k || !p->h_fused_err) return SDRK_OK;
+    unsigned bad = 0;
+    for (unsigned i = 0; i < FUSED_MAILBOX; ++i) {
+        bad |= p->h_fused_err[i];
+        p->h_fused_err[i] = 0;
+    }
+    if (bad) return fail(SDRK_ERR_HIP, "fused N=65536 kernel reported an internal synchronisation error (code %u)", bad);
     return SDRK_OK;
 }
 
@@ -171,7 +212,7 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
     if (st != SDRK_OK) return st;
     HIP_TRY(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    return SDRK_OK;
+    return fused_check(p);
 }
 
 }  // namespace
@@ -335,6 +376,15 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
         p->scratch_frames = frames;
         PLAN_TRY(hipMalloc((void**)&p->d_scratch, frames * (size_t)nfft * sizeof(float2)));
     }
+    if (nfft == 65536) {
+        const char* env = getenv("SDRK_FUSED64K");   // default on; SDRK_FUSED64K=0 selects the two-launch tiled path
+        p->fused64k = !(env && env[0] == '0');
+        if (p->fused64k) {
+            PLAN_TRY(hipMalloc(&p->d_fused_ring, sdrk::fused64k_ring_bytes()));
+            PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * sizeof(unsigned), hipHostMallocDefault));
+            memset(p->h_fused_err, 0, FUSED_MAILBOX * sizeof(unsigned));
+        }
+    }
 #undef PLAN_TRY
     *out = p;
     return SDRK_OK;
@@ -348,6 +398,9 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_tw_big) (void)hipFree(p->d_tw_big);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_fused_ring) (void)hipFree(p->d_fused_ring);
+    if (p->d_fused_ctrl) (void)hipFree(p->d_fused_ctrl);
+    if (p->h_fused_err) (void)hipHostFree(p->h_fused_err);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -418,7 +471,7 @@ int sdrk_plan_sync(sdrk_plan* p) {
     if (!p) return fail(SDRK_ERR_INVALID, "plan is NULL");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    return SDRK_OK;
+    return fused_check(p);
 }
 
 int sdrk_exec_device_timed(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride,
@@ -435,7 +488,7 @@ int sdrk_exec_device_timed(sdrk_plan* p, const void* d_iq, size_t n_frames, size
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     HIP_TRY(hipEventSynchronize(p->ev1));
     HIP_TRY(hipEventElapsedTime(elapsed_ms, p->ev0, p->ev1));
-    return SDRK_OK;
+    return fused_check(p);
 }
 
 int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,

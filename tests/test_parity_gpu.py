@@ -446,3 +446,42 @@ def test_waterfall_decimated_readout(pkg):
     big.append(x)
     full = big.as_array()
     assert np.array_equal(big.as_array(decimate=256), full.reshape(2, 4096, 256).max(-1))
+
+
+def test_fused_n65536_bit_identical_to_two_launch_path(pkg, monkeypatch):
+    """The XCD-resident fused kernel (fft_fused64k.hip) does the same arithmetic as the two tiled
+    launches; any stale read of the L2-resident intermediate would show as a differing bit.
+    3000 frames (1.5 GiB) keeps every XCD's ring wrapping hundreds of times under load."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    n, nf = 65536, 3000
+    d_in, d_a, d_b = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, (nf + 1) * n * 8, ctypes.byref(d_in)))
+    _ffi.check(lib.sdrk_dev_alloc(0, 2 * nf * n * 4, ctypes.byref(d_a)))
+    _ffi.check(lib.sdrk_dev_alloc(0, 2 * nf * n * 4, ctypes.byref(d_b)))
+    try:
+        _ffi.check(lib.sdrk_synth_fill(0, 77, 0, (nf + 1) * 16, 4096, d_in, None))
+        monkeypatch.setenv("SDRK_FUSED64K", "1")
+        fused = SpectrumPlan(n, window="hann")
+        monkeypatch.setenv("SDRK_FUSED64K", "0")
+        tiled = SpectrumPlan(n, window="hann")
+        a = np.empty(n, dtype=np.uint32)
+        b = np.empty(n, dtype=np.uint32)
+        for stride, rows in ((n, nf), (n // 2, 2 * nf - 1)):          # packed frames, then 50 % overlap
+            for _ in range(3):                                         # repeat: ring slots hot in L1/L2
+                fused.exec_device(d_in.value, rows, d_a.value, frame_stride=stride)
+            fused.sync()
+            tiled.exec_device(d_in.value, rows, d_b.value, frame_stride=stride)
+            tiled.sync()
+            step = 37
+            for f in list(range(0, rows, step)) + [rows - 1]:
+                _ffi.check(lib.sdrk_memcpy_d2h(0, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_a.value + f * n * 4), n * 4))
+                _ffi.check(lib.sdrk_memcpy_d2h(0, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_b.value + f * n * 4), n * 4))
+                assert np.array_equal(a, b), f"frame {f} (stride {stride}) differs"
+        fused.close()
+        tiled.close()
+    finally:
+        for d in (d_in, d_a, d_b):
+            lib.sdrk_dev_free(0, d)
