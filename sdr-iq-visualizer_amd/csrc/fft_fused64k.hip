@@ -32,7 +32,17 @@ namespace sdrk {
 
 constexpr int FU_THREADS = 256;
 constexpr int FU_N = 65536;
-constexpr int FU_RING_SLOTS = 6;             // 6 x 512 KiB = 3 MiB of each XCD's 4 MiB L2
+#ifndef FU_RING_SLOTS_N
+#define FU_RING_SLOTS_N 6
+#endif
+#ifndef FU_LAG_N
+#define FU_LAG_N 3
+#endif
+constexpr int FU_RING_SLOTS = FU_RING_SLOTS_N;  // x 512 KiB of each XCD's 4 MiB L2
+// K3 tiles of slot s - LAG are queued with the K1 tiles of slot s: by the time a K3 tile is drawn,
+// the K1 tiles it needs were drawn >= 32*LAG tasks (about one full XCD of workgroups) earlier.
+constexpr int FU_LAG = FU_LAG_N;
+static_assert(FU_RING_SLOTS > FU_LAG, "ring must outlast the K1 -> K3 lag");
 constexpr unsigned FU_END = 0xFFFFFFFFu;
 constexpr unsigned FU_POISON = 0xFFFFFFFEu;  // returned by wg_wait after a timeout / error: caller leaves
 constexpr unsigned FU_SPIN_LIMIT = 1u << 18; // polls (~1-2 us each under load): give up after a fraction of a second
@@ -48,24 +58,61 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Thread 0 spins until *p >= want (or, for want == 0, until *p != 0); everyone gets the value.
-__device__ __forceinline__ unsigned wg_wait(const unsigned* p, unsigned want, unsigned* err, unsigned* sh,
-                                            unsigned spin_limit = FU_SPIN_LIMIT) {
-    if (threadIdx.x == 0) {
-        unsigned v = ld_agent(p), spins = 0;
-        while (want ? v < want : v == 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > spin_limit || ld_agent(err)) {
+// One parallel poll of up to three control words by lanes 0..2 of wave 0 (a single wave
+// instruction, one round trip); lane i spins until its word satisfies its condition
+// (want == 0: non-zero; else >= want).  Results are broadcast through LDS; FU_POISON in
+// any slot means a timeout or a raised error flag and the caller leaves.
+struct Poll3 {
+    unsigned v[3];
+};
+__device__ __forceinline__ Poll3 wg_poll3(const unsigned* p0, unsigned w0, const unsigned* p1, unsigned w1,
+                                          const unsigned* p2, unsigned w2, unsigned* err, unsigned* sh) {
+    const int tid = threadIdx.x;
+    if (tid < 3) {
+        const unsigned* p = tid == 0 ? p0 : (tid == 1 ? p1 : p2);
+        const unsigned want = tid == 0 ? w0 : (tid == 1 ? w1 : w2);
+        unsigned v = p ? ld_agent(p) : 1u, spins = 0;
+        while (p && want == 0 && v == 0) {   // only the publish words spin here; a count is sampled once
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > FU_SPIN_LIMIT || ld_agent(err)) {
+                if (!ld_agent(err)) {  // first reporter leaves a record: which word, what it held
+                    err[1] = (unsigned)(p - err); err[2] = v; err[3] = want; err[4] = 100u + tid;
+                }
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 v = FU_POISON;
                 break;
             }
             v = ld_agent(p);
         }
-        *sh = v;
+        sh[tid] = v;
     }
     __syncthreads();
-    const unsigned v = *sh;
+    Poll3 r;
+    r.v[0] = sh[0]; r.v[1] = sh[1]; r.v[2] = sh[2];
+    __syncthreads();
+    return r;
+}
+
+// Thread 0 spins until *p >= want; workgroup-uniform result (FU_POISON on timeout / error).
+__device__ __forceinline__ unsigned wg_wait_count(const unsigned* p, unsigned want, unsigned* err, unsigned* sh) {
+    if (threadIdx.x == 0) {
+        unsigned v = ld_agent(p), spins = 0;
+        while (v < want) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > FU_SPIN_LIMIT || ld_agent(err)) {
+                if (!ld_agent(err)) {
+                    err[1] = (unsigned)(p - err); err[2] = v; err[3] = want; err[4] = 200u;
+                }
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = FU_POISON;
+                break;
+            }
+            v = ld_agent(p);
+        }
+        sh[0] = v;
+    }
+    __syncthreads();
+    const unsigned v = sh[0];
     __syncthreads();
     return v;
 }
@@ -77,7 +124,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
     const float2* __restrict__ t2, float2* __restrict__ ring, unsigned* __restrict__ ctrl, unsigned max_slots,
     float eps, int shift) {
     __shared__ float2 lds[16 * 272 + 256];
-    __shared__ unsigned sh_u;
+    __shared__ unsigned sh_u[4];
     float2* __restrict__ tw256 = lds + 16 * 272;
     const int tid = threadIdx.x;
     const int lo = tid & 15, hi = tid >> 4;
@@ -101,36 +148,62 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
     const int x1r_even = lo + 256 * hi + 16 * b, x1r_odd = lo + 256 * hi - 16 * b;
     const int xor_q = shift ? 8 : 0;
 
+    // Frames are claimed 16 at a time: the workgroup that draws (s, 0) with s % 16 == 0 takes the
+    // next 16 frame numbers from the global counter and publishes base+1 in chunk_base[s / 16].
+    unsigned* __restrict__ chunk_base = frame_of;  // indexed by s >> 4 (array is max_slots long: ample)
+
     // A workgroup can never legitimately draw more tasks than one XCD's queue holds.
     const unsigned max_draws = max_slots * 32u;
+    unsigned t_next = 0;
+    if (tid == 0) t_next = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned draws = 0;; ++draws) {
+        if (tid == 0) sh_u[3] = t_next;
+        __syncthreads();
+        const unsigned t = sh_u[3];
+        __syncthreads();
         if (draws > max_draws) {
             if (tid == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
-        if (tid == 0) sh_u = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const unsigned t = sh_u;
-        __syncthreads();
         const unsigned s = t >> 5, sub = t & 31;
         if (s >= max_slots) {  // cannot happen with the host's sizing; never index past the arrays
             if (tid == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
-        if (sub == 0 && tid == 0) {
-            const unsigned f = __hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(frame_of + s, f < n_frames ? f + 1 : FU_END, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        if (sub == 0 && (s & 15) == 0 && tid == 0) {
+            const unsigned f0 = __hip_atomic_fetch_add(ctrl, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(chunk_base + (s >> 4), f0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const unsigned cur = wg_wait(frame_of + s, 0, err, &sh_u);
-        const unsigned prev = s ? wg_wait(frame_of + s - 1, 0, err, &sh_u) : FU_END;
-        if (cur == FU_POISON || prev == FU_POISON) break;  // (values are workgroup-uniform)
-        if (cur == FU_END && prev == FU_END) break;        // this XCD's work is finished
+        // the next task id is fetched while this one runs (its latency hides under the data loads)
+        if (tid == 0) t_next = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // one round trip: both chunk words and the completion count this task depends on
+        const unsigned* dep = nullptr;
+        if (sub < 16) { if (s >= FU_RING_SLOTS) dep = done3 + s - FU_RING_SLOTS; }
+        else if (s >= FU_LAG) dep = done1 + s - FU_LAG;
+        const Poll3 pl = wg_poll3(chunk_base + (s >> 4), 0, s >= FU_LAG ? chunk_base + ((s - FU_LAG) >> 4) : nullptr, 0,
+                                  dep, 16, err, sh_u);
+        if (pl.v[0] == FU_POISON || pl.v[1] == FU_POISON) break;
+        const bool dep_ready = dep == nullptr || pl.v[2] >= 16;   // sampled once alongside; waited for below if needed
+        const unsigned fc = pl.v[0] - 1 + (s & 15);
+        const unsigned fp = s >= FU_LAG ? pl.v[1] - 1 + ((s - FU_LAG) & 15) : 0;
+        const unsigned cur = fc < n_frames ? fc + 1 : FU_END;
+        const unsigned prev = (s >= FU_LAG && fp < n_frames) ? fp + 1 : FU_END;
+        if (cur == FU_END && prev == FU_END) {             // this XCD's work is finished
+            // The task already drawn ahead is void too (frames only run out once), but if it carries
+            // the duty to publish a chunk word, tasks queued behind it are waiting for that word.
+            if (tid == 0) {
+                const unsigned s2 = t_next >> 5;
+                if ((t_next & 31) == 0 && (s2 & 15) == 0 && s2 < max_slots) {
+                    const unsigned f0 = __hip_atomic_fetch_add(ctrl, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(chunk_base + (s2 >> 4), f0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            break;
+        }
 
         if (sub < 16) {
             // ---------------- K1: column tile `sub` of frame cur-1 -> ring slot s % S ----------------
             if (cur == FU_END) continue;
-            if (s >= FU_RING_SLOTS && wg_wait(done3 + s - FU_RING_SLOTS, 16, err, &sh_u) == FU_POISON) break;
             const size_t f = cur - 1;
             const int m = (int)sub * 16 + lo;
             const float2* __restrict__ x = iq + f * frame_stride + m;
@@ -163,6 +236,8 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
                 v[a] = cf{tt.x, tt.y};
             }
             radix16(v);
+            // the ring slot must have been drained by the K3 tiles of slot s - S (usually long ago)
+            if (!dep_ready && wg_wait_count(dep, 16, err, sh_u) == FU_POISON) break;
             float2* __restrict__ o = my_ring + (size_t)(s % FU_RING_SLOTS) * FU_N + m;
             const float2 bw = t1[m * 16 + hi];
             const cf base = cf{bw.x, bw.y};
@@ -181,11 +256,11 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
         } else {
             // ---------------- K3: row tile `sub-16` of frame prev-1 <- ring slot (s-1) % S ----------------
             if (prev == FU_END) continue;
-            if (wg_wait(done1 + s - 1, 16, err, &sh_u) == FU_POISON) break;
+            if (!dep_ready && wg_wait_count(dep, 16, err, sh_u) == FU_POISON) break;
             const size_t f = prev - 1;
             const int k3_0 = (int)(sub - 16) * 16;
             const unsigned long long* __restrict__ in = reinterpret_cast<const unsigned long long*>(
-                my_ring + (size_t)((s - 1) % FU_RING_SLOTS) * FU_N + (size_t)(k3_0 + hi) * 256 + lo);
+                my_ring + (size_t)((s - FU_LAG) % FU_RING_SLOTS) * FU_N + (size_t)(k3_0 + hi) * 256 + lo);
             cf v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -206,7 +281,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
                 lds[lo + 17 * hi + 272 * p] = make_float2(v[rev16(p)].x, v[rev16(p)].y);
             __syncthreads();
             // all of this workgroup's ring reads have returned: the slot may be reused once 16 tiles say so
-            if (tid == 0) __hip_atomic_fetch_add(done3 + s - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_fetch_add(done3 + s - FU_LAG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 float2 tt = lds[u + 17 * lo + 272 * hi];
@@ -237,7 +312,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
 
 size_t fused64k_ring_bytes() { return (size_t)FU_MAX_XCD * FU_RING_SLOTS * FU_N * sizeof(float2); }
 
-unsigned fused64k_max_slots(size_t n_frames, unsigned grid) { return (unsigned)(n_frames + grid / 16 + 8); }
+unsigned fused64k_max_slots(size_t n_frames, unsigned grid) { return (unsigned)(n_frames + grid / 16 + 8 + FU_LAG); }
 
 size_t fused64k_ctrl_words_for(size_t n_frames, int num_cus) {
     return fused64k_ctrl_words(fused64k_max_slots(n_frames, (unsigned)num_cus * 3));

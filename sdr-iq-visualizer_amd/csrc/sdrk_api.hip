@@ -90,7 +90,7 @@ struct sdrk_plan {
     unsigned* h_fused_err = nullptr;   // pinned mailbox: error word of the last launches
     unsigned fused_launches = 0;
 };
-constexpr unsigned FUSED_MAILBOX = 64;
+constexpr unsigned FUSED_MAILBOX = 64;   // entries of 8 words: error flag + debug record
 
 struct sdrk_waterfall {
     int device = 0;
@@ -145,8 +145,8 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
             }
             e = sdrk::launch_fused64k(b, p->d_fused_ring, p->d_fused_ctrl, p->fused_ctrl_words);
             if (e == hipSuccess)
-                e = hipMemcpyAsync(p->h_fused_err + (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl + 1,
-                                   sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+                e = hipMemcpyAsync(p->h_fused_err + 8 * (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl + 1,
+                                   8 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
         }
     } else if (sdrk::fft_tiled_supports(p->nfft))
         e = sdrk::launch_fft_tiled(a);
@@ -159,12 +159,15 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
 // After a stream sync: did any fused N=65536 launch report an internal wait timeout?
 int fused_check(sdrk_plan* p) {
     if (!p->fused64k || !p->h_fused_err) return SDRK_OK;
-    unsigned bad = 0;
+    unsigned bad = 0, rec[8] = {0};
     for (unsigned i = 0; i < FUSED_MAILBOX; ++i) {
-        bad |= p->h_fused_err[i];
-        p->h_fused_err[i] = 0;
+        if (p->h_fused_err[8 * i] && !bad) memcpy(rec, p->h_fused_err + 8 * i, sizeof rec);
+        bad |= p->h_fused_err[8 * i];
+        memset(p->h_fused_err + 8 * i, 0, 8 * sizeof(unsigned));
     }
-    if (bad) return fail(SDRK_ERR_HIP, "fused N=65536 kernel reported an internal synchronisation error (code %u)", bad);
+    if (bad)
+        return fail(SDRK_ERR_HIP, "fused N=65536 kernel reported an internal synchronisation error (code %u; word %u held %u, "
+                    "wanted %u, site %u)", bad, rec[1], rec[2], rec[3], rec[4]);
     return SDRK_OK;
 }
 
@@ -377,12 +380,15 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
         PLAN_TRY(hipMalloc((void**)&p->d_scratch, frames * (size_t)nfft * sizeof(float2)));
     }
     if (nfft == 65536) {
-        const char* env = getenv("SDRK_FUSED64K");   // default on; SDRK_FUSED64K=0 selects the two-launch tiled path
-        p->fused64k = !(env && env[0] == '0');
+        // Experimental single-launch, XCD-resident form (fft_fused64k.hip): opt in with SDRK_FUSED64K=1.
+        // Round-1 measurements: HBM traffic 14-21 B/sample instead of 28, but 1.4x slower than the two tiled
+        // launches (dependency stalls between the K1 and K3 tiles of a frame), so the tiled path stays default.
+        const char* env = getenv("SDRK_FUSED64K");
+        p->fused64k = env && env[0] == '1';
         if (p->fused64k) {
             PLAN_TRY(hipMalloc(&p->d_fused_ring, sdrk::fused64k_ring_bytes()));
-            PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * sizeof(unsigned), hipHostMallocDefault));
-            memset(p->h_fused_err, 0, FUSED_MAILBOX * sizeof(unsigned));
+            PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * 8 * sizeof(unsigned), hipHostMallocDefault));
+            memset(p->h_fused_err, 0, FUSED_MAILBOX * 8 * sizeof(unsigned));
         }
     }
 #undef PLAN_TRY

@@ -448,9 +448,10 @@ def test_waterfall_decimated_readout(pkg):
     assert np.array_equal(big.as_array(decimate=256), full.reshape(2, 4096, 256).max(-1))
 
 
-def test_fused_n65536_bit_identical_to_two_launch_path(pkg, monkeypatch):
+def test_fused_n65536_agrees_with_two_launch_path(pkg, monkeypatch):
     """The XCD-resident fused kernel (fft_fused64k.hip) does the same arithmetic as the two tiled
-    launches; any stale read of the L2-resident intermediate would show as a differing bit.
+    launches (differences: FMA contraction in separately compiled code, i.e. last-bit level); a stale
+    or early read of the L2-resident intermediate would be a gross error in a whole tile.
     3000 frames (1.5 GiB) keeps every XCD's ring wrapping hundreds of times under load."""
     import ctypes
     from sdr_iq_visualizer_amd import _ffi
@@ -467,8 +468,8 @@ def test_fused_n65536_bit_identical_to_two_launch_path(pkg, monkeypatch):
         fused = SpectrumPlan(n, window="hann")
         monkeypatch.setenv("SDRK_FUSED64K", "0")
         tiled = SpectrumPlan(n, window="hann")
-        a = np.empty(n, dtype=np.uint32)
-        b = np.empty(n, dtype=np.uint32)
+        a = np.empty(n, dtype=np.float32)
+        b = np.empty(n, dtype=np.float32)
         for stride, rows in ((n, nf), (n // 2, 2 * nf - 1)):          # packed frames, then 50 % overlap
             for _ in range(3):                                         # repeat: ring slots hot in L1/L2
                 fused.exec_device(d_in.value, rows, d_a.value, frame_stride=stride)
@@ -479,7 +480,7 @@ def test_fused_n65536_bit_identical_to_two_launch_path(pkg, monkeypatch):
             for f in list(range(0, rows, step)) + [rows - 1]:
                 _ffi.check(lib.sdrk_memcpy_d2h(0, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_a.value + f * n * 4), n * 4))
                 _ffi.check(lib.sdrk_memcpy_d2h(0, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_b.value + f * n * 4), n * 4))
-                assert np.array_equal(a, b), f"frame {f} (stride {stride}) differs"
+                assert peak_rel_err(a, b) <= 5e-6, f"frame {f} (stride {stride}) differs"   # one ulp of a 116 dB value is 9e-7
         fused.close()
         tiled.close()
     finally:
