@@ -188,7 +188,9 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
         const unsigned fp = s >= FU_LAG ? pl.v[1] - 1 + ((s - FU_LAG) & 15) : 0;
         const unsigned cur = fc < n_frames ? fc + 1 : FU_END;
         const unsigned prev = (s >= FU_LAG && fp < n_frames) ? fp + 1 : FU_END;
-        if (cur == FU_END && prev == FU_END) {             // this XCD's work is finished
+        // Finished only when the frames ran out at least LAG slots ago: then every later task is void too
+        // (K1 of an END slot; K3 of a slot >= the first END slot).  For s < LAG there is no "prev" slot yet.
+        if (cur == FU_END && s >= FU_LAG && prev == FU_END) {
             // The task already drawn ahead is void too (frames only run out once), but if it carries
             // the duty to publish a chunk word, tasks queued behind it are waiting for that word.
             if (tid == 0) {
