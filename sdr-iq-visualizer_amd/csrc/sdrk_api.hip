@@ -82,6 +82,10 @@ struct sdrk_plan {
     size_t in_cap = 0;
     void* d_out = nullptr;
     size_t out_cap = 0;
+    // small-call fast path of sdrk_exec_host: pinned, device-mapped staging the kernel reads and
+    // writes directly over PCIe (no DMA-engine copies for a 32 KiB frame)
+    void* h_small_in = nullptr;
+    void* h_small_out = nullptr;
     // N = 65536 fused path (fft_fused64k.hip)
     bool fused64k = false;
     void* d_fused_ring = nullptr;
@@ -90,6 +94,7 @@ struct sdrk_plan {
     unsigned* h_fused_err = nullptr;   // pinned mailbox: error word of the last launches
     unsigned fused_launches = 0;
 };
+constexpr size_t SMALL_IN_BYTES = 256 << 10;   // calls up to this much input take the zero-copy path
 constexpr unsigned FUSED_MAILBOX = 64;   // entries of 8 words: error flag + debug record
 
 struct sdrk_waterfall {
@@ -206,6 +211,23 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
     const size_t in_bytes = in_samples * sizeof(float2);
     const size_t out_elem = epilogue == sdrk::EPI_LOGPSD ? sizeof(float) : sizeof(float2);
     const size_t out_bytes = n_frames * (size_t)p->nfft * out_elem;
+    if (in_bytes <= SMALL_IN_BYTES && out_bytes <= SMALL_IN_BYTES && p->nfft <= 4096) {
+        // The live app's call shape (one 4096-sample buffer per call, streamer.py:114-121): latency matters,
+        // not bandwidth.  The kernel reads the frame from, and writes the row to, pinned host memory.
+        if (!p->h_small_in) {
+            HIP_TRY(hipHostMalloc(&p->h_small_in, SMALL_IN_BYTES, hipHostMallocMapped));
+            HIP_TRY(hipHostMalloc(&p->h_small_out, SMALL_IN_BYTES, hipHostMallocMapped));
+        }
+        void *d_si = nullptr, *d_so = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d_si, p->h_small_in, 0));
+        HIP_TRY(hipHostGetDevicePointer(&d_so, p->h_small_out, 0));
+        memcpy(p->h_small_in, iq, in_bytes);
+        st = plan_launch(p, d_si, n_frames, frame_stride, d_so, epilogue, p->stream);
+        if (st != SDRK_OK) return st;
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        memcpy(out, p->h_small_out, out_bytes);
+        return SDRK_OK;
+    }
     st = grow(p->device, &p->d_in, &p->in_cap, in_bytes);
     if (st != SDRK_OK) return st;
     st = grow(p->device, &p->d_out, &p->out_cap, out_bytes);
@@ -404,6 +426,8 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_tw_big) (void)hipFree(p->d_tw_big);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->h_small_in) (void)hipHostFree(p->h_small_in);
+    if (p->h_small_out) (void)hipHostFree(p->h_small_out);
     if (p->d_fused_ring) (void)hipFree(p->d_fused_ring);
     if (p->d_fused_ctrl) (void)hipFree(p->d_fused_ctrl);
     if (p->h_fused_err) (void)hipHostFree(p->h_fused_err);

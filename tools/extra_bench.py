@@ -27,10 +27,10 @@ import sdr_iq_visualizer_amd as pkg  # noqa: E402
 
 def host_boundary(quick):
     out = []
-    for b in ((1, 256, 4096) if quick else (1, 256, 4096, 32768)):
+    for b in ((1, 4, 256, 4096) if quick else (1, 4, 8, 16, 256, 4096, 32768)):
         x = synth.synth_iq(1, 0, b, 4096)
         pkg.spectrum_db(x)                                  # plan + staging warm-up
-        reps = 200 if b == 1 else 5
+        reps = 500 if b <= 16 else 5
         t0 = time.perf_counter()
         for _ in range(reps):
             pkg.spectrum_db(x)
