@@ -75,6 +75,17 @@ int main(int argc, char** argv) {
     sdrk::LaunchArgs a; a.d_iq = d_in; a.frame_stride = 4096; a.d_out = d_out; a.n_frames = nf; a.nfft = 4096;
     a.d_window = win ? d_win : nullptr; a.d_twiddle = d_tw; a.stream = s; a.num_cus = prop.multiProcessorCount;
     time_it("fft4096 fused", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+    if (argc > 4) {   // placement experiment: same kernel, output (or input) buffer shifted / re-allocated
+        for (size_t off : {(size_t)4096, (size_t)65536, (size_t)1 << 20, (size_t)3 << 20, (size_t)64 << 20}) {
+            void* d_out2; CK(hipMalloc(&d_out2, nf * 4096 * 4 + off + (128 << 20)));
+            a.d_out = (char*)d_out2 + off;
+            char name[64]; snprintf(name, sizeof name, "  new out alloc +%zu KiB", off >> 10);
+            time_it(name, reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+            CK(hipFree(d_out2));
+        }
+        a.d_out = d_out;
+        time_it("  original buffers again", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+    }
     // checksum of a few outputs so variants can be compared for equality
     std::vector<float> h(4096 * 2);
     CK(hipMemcpy(h.data(), (float*)d_out + (nf - 2) * 4096, 4096 * 2 * 4, hipMemcpyDeviceToHost));

@@ -348,7 +348,8 @@ def test_streamer_shim_on_gpu(pkg):
     """The reader loop with the GPU transform: dicts as the dashboard reads them."""
     import time
     from sdr_iq_visualizer_amd import streaming, synth
-    s = streaming.SpectrumStreamer(streaming.SyntheticSource(nfft=4096, seed=77, tone_bin=512.0), queue_size=100)
+    # queue large enough that the (fast) producer never drops frame 0 before we read it
+    s = streaming.SpectrumStreamer(streaming.SyntheticSource(nfft=4096, seed=77, tone_bin=512.0), queue_size=1_000_000)
     assert s.start_streaming()
     deadline = time.time() + 20
     while s.total_frames < 20 and time.time() < deadline:
