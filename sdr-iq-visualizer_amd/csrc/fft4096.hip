@@ -29,9 +29,6 @@
 // transformed, so each resident workgroup keeps 32 KiB of HBM reads outstanding.
 #include "fft4096_core.h"
 
-#ifndef F4K_FASTLOG
-#define F4K_FASTLOG 0  // 1: skip the sqrt when |X| >= eps*2^25 on every lane of the wave
-#endif
 #ifndef F4K_WINREG
 #define F4K_WINREG 0   // 1: window coefficients in 16 VGPRs per thread instead of a 16 KiB LDS copy
 #endif
@@ -41,7 +38,10 @@
 
 namespace sdrk {
 
-template <bool HAS_WINDOW, int EPILOGUE>
+// FASTLOG: when every lane of the wave has |X| >= eps * 2^25 on all its 16 bins, |X| + eps rounds to |X|
+// and 20*log10(|X| + eps) = 10*log10(|X|^2): the square root and the add are skipped (wave-uniform branch;
+// any smaller value, zero or NaN in the wave takes the reference-order path).
+template <bool HAS_WINDOW, int EPILOGUE, bool FASTLOG>
 __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     const float2* __restrict__ iq, size_t frame_stride, void* __restrict__ out_raw,
     size_t n_frames, const float* __restrict__ window, const float2* __restrict__ tw4096,
@@ -69,9 +69,7 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     __syncthreads();
 
     const int xor_k2 = shift ? 8 : 0;
-#if F4K_FASTLOG
     const float fast_thresh = (eps * 33554432.0f) * (eps * 33554432.0f);  // (eps * 2^25)^2
-#endif
     const int voff_in = tid * 8;
     constexpr int OUT_ELEM = (EPILOGUE == EPI_LOGPSD ? 4 : 8);
     const int voff_out = tid * OUT_ELEM;
@@ -115,8 +113,9 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
         __amdgpu_buffer_rsrc_t w = frame_rsrc(
             static_cast<char*>(out_raw) + f * (size_t)(F4K_N * OUT_ELEM), F4K_N * OUT_ELEM);
         if (EPILOGUE == EPI_LOGPSD) {
-#if F4K_FASTLOG
+            bool fast = false;
             float p[16], pmin;
+            if (FASTLOG) {
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 cf z = v[rev16(k2)];
@@ -126,14 +125,14 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
             pmin = fminf(pmin, fminf(fminf(fminf(p[8], p[9]), fminf(p[10], p[11])),
                                      fminf(fminf(p[12], p[13]), fminf(p[14], p[15]))));
             // NaN compares false -> slow path, which propagates it like the reference does.
-            if (__builtin_amdgcn_ballot_w64(!(pmin >= fast_thresh)) == 0) {
+            fast = __builtin_amdgcn_ballot_w64(!(pmin >= fast_thresh)) == 0;
+            }
+            if (FASTLOG && fast) {
 #pragma unroll
                 for (int k2 = 0; k2 < 16; ++k2)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, logpsd_db_fast(p[k2])), w,
                                                           voff_out, (k2 ^ xor_k2) * 1024, F4K_NT);
-            } else
-#endif
-            {
+            } else {
 #pragma unroll
                 for (int k2 = 0; k2 < 16; ++k2) {
                     cf z = v[rev16(k2)];
@@ -162,13 +161,17 @@ hipError_t launch_fft4096(const LaunchArgs& a) {
     dim3 g(grid), b(F4K_THREADS);
     const float2* iq = static_cast<const float2*>(a.d_iq);
     const float2* tw = static_cast<const float2*>(a.d_twiddle);
-#define SDRK_LAUNCH(W, E)                                                                   \
-    hipLaunchKernelGGL((fft4096_kernel<W, E>), g, b, 0, a.stream, iq, a.frame_stride, a.d_out, \
+#define SDRK_LAUNCH(W, E, F)                                                                   \
+    hipLaunchKernelGGL((fft4096_kernel<W, E, F>), g, b, 0, a.stream, iq, a.frame_stride, a.d_out, \
                        a.n_frames, a.d_window, tw, a.eps, a.shift)
     if (a.epilogue == EPI_LOGPSD) {
-        if (a.d_window) SDRK_LAUNCH(true, EPI_LOGPSD); else SDRK_LAUNCH(false, EPI_LOGPSD);
+        if (a.fast_log) {
+            if (a.d_window) SDRK_LAUNCH(true, EPI_LOGPSD, true); else SDRK_LAUNCH(false, EPI_LOGPSD, true);
+        } else {
+            if (a.d_window) SDRK_LAUNCH(true, EPI_LOGPSD, false); else SDRK_LAUNCH(false, EPI_LOGPSD, false);
+        }
     } else {
-        if (a.d_window) SDRK_LAUNCH(true, EPI_COMPLEX); else SDRK_LAUNCH(false, EPI_COMPLEX);
+        if (a.d_window) SDRK_LAUNCH(true, EPI_COMPLEX, false); else SDRK_LAUNCH(false, EPI_COMPLEX, false);
     }
 #undef SDRK_LAUNCH
     return hipGetLastError();

@@ -71,10 +71,15 @@ int main(int argc, char** argv) {
     CK(sdrk::launch_synth_fill(1234, 0, nf, 4096, d_in, s)); CK(hipStreamSynchronize(s));
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     double bytes = 12.0 * nf * 4096;
-    printf("variant: WAVES=%d TWCHAIN=%d FASTLOG=%d NT=%d ABLATE=%d  frames=2^%d window=%d\n", F4K_WAVES, F4K_TWCHAIN, F4K_FASTLOG, F4K_NT, F4K_ABLATE, lg, win);
+    printf("variant: WAVES=%d TWCHAIN=%d FASTLOG=%d NT=%d ABLATE=%d  frames=2^%d window=%d\n", F4K_WAVES, F4K_TWCHAIN, -1, F4K_NT, F4K_ABLATE, lg, win);
     sdrk::LaunchArgs a; a.d_iq = d_in; a.frame_stride = 4096; a.d_out = d_out; a.n_frames = nf; a.nfft = 4096;
     a.d_window = win ? d_win : nullptr; a.d_twiddle = d_tw; a.stream = s; a.num_cus = prop.multiProcessorCount;
-    time_it("fft4096 fused", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+    for (int round = 0; round < 3; ++round) {   // interleaved A/B on the same buffers
+        a.fast_log = false;
+        time_it("fft4096 reference-order log", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+        a.fast_log = true;
+        time_it("fft4096 fast log", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+    }
     if (argc > 4) {   // placement experiment: same kernel, output (or input) buffer shifted / re-allocated
         for (size_t off : {(size_t)4096, (size_t)65536, (size_t)1 << 20, (size_t)3 << 20, (size_t)64 << 20}) {
             void* d_out2; CK(hipMalloc(&d_out2, nf * 4096 * 4 + off + (128 << 20)));
