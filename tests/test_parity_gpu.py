@@ -487,3 +487,25 @@ def test_fused_n65536_agrees_with_two_launch_path(pkg, monkeypatch):
     finally:
         for d in (d_in, d_a, d_b):
             lib.sdrk_dev_free(0, d)
+
+
+def test_channel_bank_config5_shape(pkg):
+    """BASELINE.json config 5 in miniature: independent channels (here two, both on GPU 0), N = 2^20,
+    rows appended on the device, decimated host gather; each channel equals the single-channel path."""
+    from sdr_iq_visualizer_amd import synth
+    from sdr_iq_visualizer_amd.channels import ChannelBank
+    n = 1 << 20
+    bank = ChannelBank(n, [0, 0], maxlen=4, window="hann")
+    chans = [synth.synth_iq(100 + c, 0, 3 * 256, 4096).reshape(3, n) for c in range(2)]
+    bank.append_iq(chans)
+    g = bank.gather(decimate=256)
+    assert g.shape == (2, 3, 4096)
+    for c in range(2):
+        ref = cpu_ref.spectrum_db(chans[c], window=np.hanning(n))
+        full = bank.rings[c].as_array()
+        assert_db_parity(full, ref, what=f"channel {c}")
+        assert np.array_equal(g[c], full.reshape(3, 4096, 256).max(-1))
+    bank.append_iq([chans[0][:1], chans[1]])                     # ragged: channel 0 gets 1 row, channel 1 gets 3
+    g2 = bank.gather()
+    assert g2.shape == (2, 4, n) and not np.isnan(g2).any()      # both rings are full (maxlen 4)
+    bank.close()
