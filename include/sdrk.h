@@ -80,7 +80,10 @@ int sdrk_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes);
 /* ---- spectrum plan -------------------------------------------------------
  * Replaces streamer.py:119,121 for frames of nfft complex64 samples:
  *     out_db[k] = 20*log10( | fftshift( fft( w * x ) ) |[k] + eps )     (float32)
- * nfft: power of two, 2 <= nfft <= 2^22 (2^SDRK_MAX_LOG2_NFFT).
+ * nfft: 2 <= nfft <= 2^22 (2^SDRK_MAX_LOG2_NFFT) for powers of two (direct kernels);
+ *       any other length 2 <= nfft <= 2^21 goes through a chirp-z (Bluestein) convolution
+ *       built from the power-of-two kernels — the reference transforms whatever
+ *       len(samples) is (streamer.py:119).
  * max_batch: largest n_frames a single sdrk_exec_host() call will be given
  *            (sizes the plan's device staging; exec_device has no such limit).
  * window_kind / window: see sdrk_window; `window` is read only for CUSTOM.

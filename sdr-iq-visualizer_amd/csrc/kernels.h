@@ -63,6 +63,13 @@ size_t fused64k_ring_bytes();
 unsigned fused64k_max_slots(size_t n_frames, unsigned grid);
 size_t fused64k_ctrl_words_for(size_t n_frames, int num_cus);
 hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl, size_t ctrl_capacity_words);
+// arbitrary frame lengths (bluestein.hip)
+hipError_t launch_blu_pre(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
+                          const void* d_chirp, void* d_a, int num_cus, hipStream_t s);
+hipError_t launch_blu_mul(const void* d_A, const void* d_B, size_t n_frames, int M, void* d_out, int num_cus,
+                          hipStream_t s);
+hipError_t launch_blu_post(const void* d_Y, const void* d_chirp, size_t n_frames, int N, int M, float eps, int shift,
+                           int epilogue, void* d_out, int num_cus, hipStream_t s);
 hipError_t launch_row_stats(const float* d_rows, size_t n_rows, int nfft, int rank, double* d_out, hipStream_t s);
 hipError_t launch_row_peaks(const float* d_rows, size_t n_rows, int nfft, const double* d_thr, int min_distance,
                             int max_peaks, int* d_idx, int* d_count, hipStream_t s);

@@ -82,6 +82,14 @@ struct sdrk_plan {
     size_t in_cap = 0;
     void* d_out = nullptr;
     size_t out_cap = 0;
+    // non-power-of-two lengths (bluestein.hip): inner power-of-two plan of size blu_m
+    sdrk_plan* blu_inner = nullptr;
+    int blu_m = 0;
+    float2* d_blu_chirp = nullptr;   // c[n] = exp(+i pi n^2 / N), n < N
+    float2* d_blu_bspec = nullptr;   // FFT_M(b)
+    float2* d_blu_a = nullptr;       // work buffers: blu_frames * M complex64 each
+    float2* d_blu_b = nullptr;
+    size_t blu_frames = 0;
     // small-call fast path of sdrk_exec_host: pinned, device-mapped staging the kernel reads and
     // writes directly over PCIe (no DMA-engine copies for a 32 KiB frame)
     void* h_small_in = nullptr;
@@ -127,8 +135,26 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
     a.d_scratch = p->d_scratch;
     a.scratch_frames = p->scratch_frames;
     a.d_twiddle_big = p->d_tw_big;
-    hipError_t e;
-    if (p->nfft == 4096)
+    hipError_t e = hipSuccess;
+    if (p->blu_inner) {
+        const int N = p->nfft, M = p->blu_m;
+        const size_t out_elem = epilogue == sdrk::EPI_LOGPSD ? sizeof(float) : sizeof(float2);
+        for (size_t f0 = 0; f0 < n_frames; f0 += p->blu_frames) {
+            const size_t nf = n_frames - f0 < p->blu_frames ? n_frames - f0 : p->blu_frames;
+            e = sdrk::launch_blu_pre(static_cast<const float2*>(d_iq) + f0 * frame_stride, frame_stride, nf, N, M,
+                                     p->d_window, p->d_blu_chirp, p->d_blu_a, p->num_cus, stream);
+            if (e != hipSuccess) break;
+            int st = plan_launch(p->blu_inner, p->d_blu_a, nf, (size_t)M, p->d_blu_b, sdrk::EPI_COMPLEX, stream);
+            if (st != SDRK_OK) return st;
+            e = sdrk::launch_blu_mul(p->d_blu_b, p->d_blu_bspec, nf, M, p->d_blu_a, p->num_cus, stream);
+            if (e != hipSuccess) break;
+            st = plan_launch(p->blu_inner, p->d_blu_a, nf, (size_t)M, p->d_blu_b, sdrk::EPI_COMPLEX, stream);
+            if (st != SDRK_OK) return st;
+            e = sdrk::launch_blu_post(p->d_blu_b, p->d_blu_chirp, nf, N, M, p->eps, p->shift, epilogue,
+                                      static_cast<char*>(d_out) + f0 * (size_t)N * out_elem, p->num_cus, stream);
+            if (e != hipSuccess) break;
+        }
+    } else if (p->nfft == 4096)
         e = sdrk::launch_fft4096(a);
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
@@ -211,7 +237,7 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
     const size_t in_bytes = in_samples * sizeof(float2);
     const size_t out_elem = epilogue == sdrk::EPI_LOGPSD ? sizeof(float) : sizeof(float2);
     const size_t out_bytes = n_frames * (size_t)p->nfft * out_elem;
-    if (in_bytes <= SMALL_IN_BYTES && out_bytes <= SMALL_IN_BYTES && p->nfft <= 4096) {
+    if (in_bytes <= SMALL_IN_BYTES && out_bytes <= SMALL_IN_BYTES && p->nfft <= 4096 && !p->blu_inner) {
         // The live app's call shape (one 4096-sample buffer per call, streamer.py:114-121): latency matters,
         // not bandwidth.  The kernel reads the frame from, and writes the row to, pinned host memory.
         if (!p->h_small_in) {
@@ -312,9 +338,9 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
                      float eps, int shift, sdrk_plan** out) {
     if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (nfft < 2 || !is_pow2(nfft) || nfft > (1 << SDRK_MAX_LOG2_NFFT))
-        return fail(SDRK_ERR_INVALID, "nfft=%d: must be a power of two in [2, 2^%d]", nfft,
-                    SDRK_MAX_LOG2_NFFT);
+    if (nfft < 2 || nfft > (1 << SDRK_MAX_LOG2_NFFT) || (!is_pow2(nfft) && nfft > (1 << (SDRK_MAX_LOG2_NFFT - 1))))
+        return fail(SDRK_ERR_INVALID, "nfft=%d: must be in [2, 2^%d] (powers of two) or [2, 2^%d] (any other length)",
+                    nfft, SDRK_MAX_LOG2_NFFT, SDRK_MAX_LOG2_NFFT - 1);
     if (max_batch == 0) return fail(SDRK_ERR_INVALID, "max_batch must be >= 1");
     if (window_kind < SDRK_WINDOW_RECT || window_kind > SDRK_WINDOW_CUSTOM)
         return fail(SDRK_ERR_INVALID, "unknown window_kind %d", window_kind);
@@ -366,6 +392,38 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
         }
         PLAN_TRY(hipMalloc((void**)&p->d_window, sizeof(float) * nfft));
         PLAN_TRY(hipMemcpy(p->d_window, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice));
+    }
+    if (!is_pow2(nfft)) {
+        // Bluestein: inner power-of-two plan of size M >= 2N-1, chirp table, spectrum of the chirp filter
+        int M = 1;
+        while (M < 2 * nfft - 1) M <<= 1;
+        p->blu_m = M;
+        size_t frames = ((size_t)128 << 20) / ((size_t)M * sizeof(float2));
+        if (frames < 1) frames = 1;
+        if (frames > max_batch) frames = max_batch;
+        p->blu_frames = frames;
+        int st2 = sdrk_plan_create(device, M, frames, SDRK_WINDOW_RECT, nullptr, 0.0f, 0, &p->blu_inner);
+        if (st2 != SDRK_OK) { sdrk_plan_destroy(p); return st2; }
+        std::vector<float2> c(nfft), b(M, make_float2(0.f, 0.f));
+        for (long long n = 0; n < nfft; ++n) {
+            const long long r = (n * n) % (2LL * nfft);          // n^2 mod 2N keeps the phase exact
+            const double ang = M_PI * (double)r / (double)nfft;
+            c[n] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            b[n] = c[n];
+            if (n) b[M - n] = c[n];
+        }
+        PLAN_TRY(hipMalloc((void**)&p->d_blu_chirp, sizeof(float2) * nfft));
+        PLAN_TRY(hipMemcpy(p->d_blu_chirp, c.data(), sizeof(float2) * nfft, hipMemcpyHostToDevice));
+        PLAN_TRY(hipMalloc((void**)&p->d_blu_a, frames * (size_t)M * sizeof(float2)));
+        PLAN_TRY(hipMalloc((void**)&p->d_blu_b, frames * (size_t)M * sizeof(float2)));
+        PLAN_TRY(hipMalloc((void**)&p->d_blu_bspec, (size_t)M * sizeof(float2)));
+        PLAN_TRY(hipMemcpy(p->d_blu_a, b.data(), sizeof(float2) * M, hipMemcpyHostToDevice));
+        st2 = plan_launch(p->blu_inner, p->d_blu_a, 1, (size_t)M, p->d_blu_bspec, sdrk::EPI_COMPLEX, p->stream);
+        if (st2 != SDRK_OK) { sdrk_plan_destroy(p); return st2; }
+        PLAN_TRY(hipStreamSynchronize(p->stream));
+        // window (if any) was uploaded above; nothing else of the power-of-two setup applies
+        *out = p;
+        return SDRK_OK;
     }
     // twiddles of the in-LDS transform
     {
@@ -426,6 +484,11 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_tw_big) (void)hipFree(p->d_tw_big);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->blu_inner) (void)sdrk_plan_destroy(p->blu_inner);
+    if (p->d_blu_chirp) (void)hipFree(p->d_blu_chirp);
+    if (p->d_blu_bspec) (void)hipFree(p->d_blu_bspec);
+    if (p->d_blu_a) (void)hipFree(p->d_blu_a);
+    if (p->d_blu_b) (void)hipFree(p->d_blu_b);
     if (p->h_small_in) (void)hipHostFree(p->h_small_in);
     if (p->h_small_out) (void)hipHostFree(p->h_small_out);
     if (p->d_fused_ring) (void)hipFree(p->d_fused_ring);

@@ -73,9 +73,11 @@ class SpectrumPlan:
     def __init__(self, nfft: int, *, window: WindowArg = None, eps: float = 1e-12,
                  shift: bool = True, device: int = 0, max_batch: int = 1 << 30):
         nfft = int(nfft)
-        if nfft < 2 or nfft & (nfft - 1) or nfft > (1 << _ffi.MAX_LOG2_NFFT):
+        pow2 = nfft >= 2 and not (nfft & (nfft - 1))
+        if nfft < 2 or nfft > (1 << _ffi.MAX_LOG2_NFFT) or (not pow2 and nfft > (1 << (_ffi.MAX_LOG2_NFFT - 1))):
             raise ValueError(
-                f"nfft={nfft}: this build transforms power-of-two frames in [2, 2^{_ffi.MAX_LOG2_NFFT}]")
+                f"nfft={nfft}: frames must have 2..2^{_ffi.MAX_LOG2_NFFT} samples (powers of two) or "
+                f"2..2^{_ffi.MAX_LOG2_NFFT - 1} (other lengths, via Bluestein)")
         kind, warr, self._wkey = _window_spec(window, nfft)
         _ffi.require_device(device)
         self.nfft = nfft

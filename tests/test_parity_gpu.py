@@ -144,9 +144,9 @@ def test_input_dtypes_and_layouts(pkg):
     ints = (rng.integers(-2048, 2048, (2, 4096)) + 1j * rng.integers(-2048, 2048, (2, 4096)))
     assert_db_parity(pkg.spectrum_db(ints), cpu_ref.spectrum_db(ints.astype(np.complex64)), what="integer IQ")
     with pytest.raises(ValueError):
-        pkg.spectrum_db(np.zeros(4095, dtype=np.complex64))       # not a power of two
-    with pytest.raises(ValueError):
         pkg.spectrum_db(np.zeros((2, 3, 8), dtype=np.complex64))
+    with pytest.raises(ValueError):
+        pkg.spectrum_db(np.zeros(1, dtype=np.complex64))          # a single sample is not a frame
 
 
 def test_process_frame_dict_contract(pkg):
@@ -509,3 +509,22 @@ def test_channel_bank_config5_shape(pkg):
     g2 = bank.gather()
     assert g2.shape == (2, 4, n) and not np.isnan(g2).any()      # both rings are full (maxlen 4)
     bank.close()
+
+
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 12, 100, 1000, 1023, 4095, 4097, 5000, 10000, 65537, 100000, 1000000])
+def test_non_power_of_two_lengths_via_bluestein(pkg, n):
+    """The reference transforms whatever len(samples) is (np.fft.fft at streamer.py:119): odd, prime and
+    composite lengths go through the chirp-z path (bluestein.hip) on top of the power-of-two kernels."""
+    rng = np.random.default_rng(n)
+    b = 3 if n <= 100000 else 1
+    x = rand_c64(rng, b, n, scale=40.0)
+    assert_db_parity(pkg.spectrum_db(x), cpu_ref.spectrum_db(x), what=f"n={n}")
+    assert_complex_parity(pkg.fft_c64(x), cpu_ref.fft(x), what=f"fft n={n}")
+    if n <= 10000:
+        w = np.hanning(n)
+        assert_db_parity(pkg.spectrum_db(x, window="hann", shift=False), cpu_ref.spectrum_db(x, window=w, shift=False),
+                         what=f"n={n} hann unshifted")
+        tone = np.exp(2j * np.pi * 2 * np.arange(n) / n).astype(np.complex64)       # on-bin tone at k=2
+        assert int(np.argmax(pkg.spectrum_db(tone))) == (n // 2 + 2) % n
+        rows = pkg.stft_db(np.tile(x[0], 3), n, max(1, n // 3))
+        assert_db_parity(rows, cpu_ref.stft_db(np.tile(x[0], 3), n, max(1, n // 3)), what=f"stft n={n}")
