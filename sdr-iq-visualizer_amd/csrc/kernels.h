@@ -53,6 +53,8 @@ __device__ __forceinline__ float logpsd_db_fast(float p) {
 hipError_t launch_fft4096(const LaunchArgs& a);
 hipError_t launch_fft_small(const LaunchArgs& a);   // 2 <= nfft <= 2048 (and 4096 for A/B)
 hipError_t launch_fft_large(const LaunchArgs& a);   // nfft > 4096 (generic two-step)
+bool fft_lds_supports(int nfft);                     // 16 .. 16384 except 4096: registers + LDS, one pass over HBM
+hipError_t launch_fft_lds(const LaunchArgs& a);
 bool fft_tiled_supports(int nfft);                   // 2^16 .. 2^20
 hipError_t launch_fft_tiled(const LaunchArgs& a);   // tiled 256 x R x 256 passes
 hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,

@@ -82,6 +82,7 @@ struct sdrk_plan {
     size_t in_cap = 0;
     void* d_out = nullptr;
     size_t out_cap = 0;
+    bool force_generic = false;      // SDRK_GENERIC=1: use the Stockham radix-2 catch-all kernels (A/B checks)
     // non-power-of-two lengths (bluestein.hip): inner power-of-two plan of size blu_m
     sdrk_plan* blu_inner = nullptr;
     int blu_m = 0;
@@ -156,6 +157,8 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
         }
     } else if (p->nfft == 4096)
         e = sdrk::launch_fft4096(a);
+    else if (sdrk::fft_lds_supports(p->nfft) && !p->force_generic)
+        e = sdrk::launch_fft_lds(a);
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
     else if (p->fused64k) {
@@ -427,7 +430,10 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
     }
     // twiddles of the in-LDS transform
     {
-        const int tn = nfft < 4096 ? nfft : 4096;
+        const char* genv = getenv("SDRK_GENERIC");
+        p->force_generic = genv && genv[0] == '1';
+        // W_N for the in-LDS kernels (N <= 16384); the 4096 table for everything built on fft4096_core.h
+        const int tn = (nfft <= 16384 && !(p->force_generic && nfft > 4096)) ? nfft : 4096;
         std::vector<float2> t(tn);
         for (int m = 0; m < tn; ++m) t[m] = twiddle(m, tn);
         PLAN_TRY(hipMalloc((void**)&p->d_twiddle, sizeof(float2) * tn));
