@@ -17,47 +17,9 @@
 // Twiddles: one table entry per thread and pass (constant across frames, kept in registers) and a
 // depth<=4 product tree for its powers.  Persistent grid; the next group's loads are prefetched
 // into registers while the current one is transformed (except at 1024 threads, for VGPRs).
-#include "fft4096_core.h"
+#include "fft_lds_core.h"
 
 namespace sdrk {
-
-template <int LOG2N>
-struct LdsCfg {
-    static constexpr int N = 1 << LOG2N;
-    static constexpr int P = (LOG2N + 3) / 4;               // passes
-    static constexpr int R0 = 1 << (LOG2N - 4 * (P - 1));   // first radix
-    static constexpr int T = N / 16;                        // threads per frame
-    static constexpr int WG = T < 256 ? 256 : T;
-    static constexpr int F = WG / T;                        // frames per workgroup pass
-    static constexpr int SLOT = N + N / 16;                 // LDS elements per frame (17/16 N)
-    static constexpr bool PREFETCH = WG <= 256;   // wider workgroups are capped at 128 VGPRs
-    static constexpr int WAVES = WG == 1024 ? 4 : (WG == 512 ? 4 : 3);  // waves/SIMD asked of the compiler
-    __host__ __device__ static constexpr int radix(int p) { return p == 0 ? R0 : 16; }
-    __host__ __device__ static constexpr int Np(int p) { return p == 0 ? N : (N / R0) >> (4 * (p - 1)); }
-    __host__ __device__ static constexpr int Mp(int p) { return Np(p) / radix(p); }
-    __host__ __device__ static constexpr int pad(int p) { return (p < P && Mp(p) < 32) ? Mp(p) : 0; }  // pad of the layout entering pass p
-};
-
-// small first-pass butterflies on v[base .. base+R)
-template <int R>
-__device__ __forceinline__ void small_bfly(cf (&v)[16], int base) {
-    if (R == 2) bfly2(v[base], v[base + 1]);
-    if (R == 4) bfly4(v[base], v[base + 1], v[base + 2], v[base + 3]);
-    if (R == 8) {
-        constexpr float R2 = 0.70710678118654752440f;
-        cf e0 = v[base], e1 = v[base + 2], e2 = v[base + 4], e3 = v[base + 6];
-        cf o0 = v[base + 1], o1 = v[base + 3], o2 = v[base + 5], o3 = v[base + 7];
-        bfly4(e0, e1, e2, e3);
-        bfly4(o0, o1, o2, o3);
-        cf t1 = cf{(o1.x + o1.y) * R2, (o1.y - o1.x) * R2};
-        cf t2 = mul_mi(o2);
-        cf t3 = cf{(o3.y - o3.x) * R2, -(o3.x + o3.y) * R2};
-        v[base] = e0 + o0; v[base + 4] = e0 - o0;
-        v[base + 1] = e1 + t1; v[base + 5] = e1 - t1;
-        v[base + 2] = e2 + t2; v[base + 6] = e2 - t2;
-        v[base + 3] = e3 + t3; v[base + 7] = e3 - t3;
-    }
-}
 
 template <int LOG2N, bool HAS_WINDOW, int EPILOGUE>
 __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_lds_kernel(
@@ -72,19 +34,8 @@ __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_l
     const int fr = tid / T, tau = tid - fr * T;
     float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
 
-    // per-thread twiddle bases, constant across frames
-    cf w0[C0];        // pass 0: W_N^(r'), r' = tau + T i
-#pragma unroll
-    for (int i = 0; i < C0; ++i) {
-        const float2 t = twN[(tau + T * i) & (N - 1)];
-        w0[i] = cf{t.x, t.y};
-    }
-    cf wp[P > 1 ? P : 1];  // passes 1..P-2: W_{N_p}^(r''), r'' = tau % M_p
-#pragma unroll
-    for (int p = 1; p < P - 1; ++p) {
-        const float2 t = twN[((tau % C::Mp(p)) * (N / C::Np(p))) & (N - 1)];
-        wp[p] = cf{t.x, t.y};
-    }
+    LdsTw<LOG2N> tw;
+    lds_tw_init<LOG2N>(tw, twN, tau);
 
     const size_t n_groups = (n_frames + F - 1) / F;
     const int xor_q = shift ? 8 : 0;
@@ -118,72 +69,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_l
                 for (int j = 0; j < R0; ++j) v[i * R0 + j] = v[i * R0 + j] * window[tau + T * (i + C0 * j)];
         }
 
-        // ---------------- pass 0 ----------------
-        if (R0 == 16) {
-            radix16(v);
-        } else {
-#pragma unroll
-            for (int i = 0; i < C0; ++i) small_bfly<R0>(v, i * R0);
-        }
-        if (P > 1) {
-            // twiddle W_N^(r' k0) and scatter to the layout entering pass 1: r' + (M_0 + pad_1) * k0
-            if (R0 == 16) {
-                cf w[16], w1 = w0[0];
-                asm volatile("" : "+v"(w1.x), "+v"(w1.y));
-                pow_tree(w1, w);
-#pragma unroll
-                for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < C0; ++i) {
-                    cf w1 = w0[i], wk = w1;
-#pragma unroll
-                    for (int k = 1; k < R0; ++k) {
-                        v[i * R0 + k] = cmul(v[i * R0 + k], wk);
-                        if (k + 1 < R0) wk = cmul(wk, w1);
-                    }
-                }
-            }
-            __syncthreads();  // previous group's last-pass reads are done
-            constexpr int S1 = C::Mp(0) + C::pad(1);
-#pragma unroll
-            for (int i = 0; i < C0; ++i)
-#pragma unroll
-                for (int k = 0; k < R0; ++k) {
-                    const cf z = v[i * R0 + (R0 == 16 ? rev16(k) : k)];
-                    lds[(tau + T * i) + S1 * k] = make_float2(z.x, z.y);
-                }
-            __syncthreads();
-        }
-        // ---------------- passes 1 .. P-1 (radix 16, one butterfly per thread) ----------------
-#pragma unroll
-        for (int p = 1; p < P; ++p) {
-            const int Mq = C::Mp(p);                       // M_p
-            const int Sin = C::Mp(p - 1) + C::pad(p);      // K stride of the layout entering pass p
-            const int Kin = tau / Mq, rr = tau - Kin * Mq; // butterfly (K, r'')
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float2 t = lds[rr + Mq * j + Sin * Kin];
-                v[j] = cf{t.x, t.y};
-            }
-            radix16(v);
-            if (p < P - 1) {
-                cf w[16], w1 = wp[p];
-                asm volatile("" : "+v"(w1.x), "+v"(w1.y));
-                pow_tree(w1, w);
-#pragma unroll
-                for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
-                __syncthreads();  // everyone has read the layout entering pass p
-                const int Sout = Mq + C::pad(p + 1);
-                const int kstep = N / C::Np(p);            // K_{p+1} = K + kstep * k_p
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const cf z = v[rev16(k)];
-                    lds[rr + Sout * (Kin + kstep * k)] = make_float2(z.x, z.y);
-                }
-                __syncthreads();
-            }
-        }
+        lds_fft_core<LOG2N, 1>(v, lds, 0, tau, tw);
         // ---------------- epilogue: X[K + (N/16) q] for K = tau (P > 1) ----------------
         const size_t f = g * F + fr;
         if (f < n_frames) {

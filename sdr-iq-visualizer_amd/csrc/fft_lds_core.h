@@ -1,0 +1,146 @@
+// fft_lds_core.h — the register + LDS transform shared by fft_lds.hip (whole frames of 16…16384
+// samples) and fft_tiled2.hip (column / row passes of the two-pass large-frame path).
+// See fft_lds.hip for the decomposition, the LDS layout rule and the twiddle scheme.
+#pragma once
+#include "fft4096_core.h"
+
+namespace sdrk {
+
+template <int LOG2N>
+struct LdsCfg {
+    static constexpr int N = 1 << LOG2N;
+    static constexpr int P = (LOG2N + 3) / 4;               // passes
+    static constexpr int R0 = 1 << (LOG2N - 4 * (P - 1));   // first radix
+    static constexpr int T = N / 16;                        // threads per frame
+    static constexpr int WG = T < 256 ? 256 : T;
+    static constexpr int F = WG / T;                        // frames per workgroup pass
+    static constexpr int SLOT = N + N / 16;                 // LDS elements per frame (17/16 N)
+    static constexpr bool PREFETCH = WG <= 256;   // wider workgroups are capped at 128 VGPRs
+    static constexpr int WAVES = WG == 1024 ? 4 : (WG == 512 ? 4 : 3);  // waves/SIMD asked of the compiler
+    __host__ __device__ static constexpr int radix(int p) { return p == 0 ? R0 : 16; }
+    __host__ __device__ static constexpr int Np(int p) { return p == 0 ? N : (N / R0) >> (4 * (p - 1)); }
+    __host__ __device__ static constexpr int Mp(int p) { return Np(p) / radix(p); }
+    __host__ __device__ static constexpr int pad(int p) { return (p < P && Mp(p) < 32) ? Mp(p) : 0; }  // pad of the layout entering pass p
+};
+
+// small first-pass butterflies on v[base .. base+R)
+template <int R>
+__device__ __forceinline__ void small_bfly(cf (&v)[16], int base) {
+    if (R == 2) bfly2(v[base], v[base + 1]);
+    if (R == 4) bfly4(v[base], v[base + 1], v[base + 2], v[base + 3]);
+    if (R == 8) {
+        constexpr float R2 = 0.70710678118654752440f;
+        cf e0 = v[base], e1 = v[base + 2], e2 = v[base + 4], e3 = v[base + 6];
+        cf o0 = v[base + 1], o1 = v[base + 3], o2 = v[base + 5], o3 = v[base + 7];
+        bfly4(e0, e1, e2, e3);
+        bfly4(o0, o1, o2, o3);
+        cf t1 = cf{(o1.x + o1.y) * R2, (o1.y - o1.x) * R2};
+        cf t2 = mul_mi(o2);
+        cf t3 = cf{(o3.y - o3.x) * R2, -(o3.x + o3.y) * R2};
+        v[base] = e0 + o0; v[base + 4] = e0 - o0;
+        v[base + 1] = e1 + t1; v[base + 5] = e1 - t1;
+        v[base + 2] = e2 + t2; v[base + 6] = e2 - t2;
+        v[base + 3] = e3 + t3; v[base + 7] = e3 - t3;
+    }
+}
+
+// Per-thread twiddle bases (constant across frames): pass 0 needs W_N^(tau + T i), pass p >= 1 needs
+// W_{N_p}^(tau % M_p); both come from the W_N table of the transform length.
+template <int LOG2N>
+struct LdsTw {
+    cf w0[16 / LdsCfg<LOG2N>::R0];
+    cf wp[LdsCfg<LOG2N>::P > 1 ? LdsCfg<LOG2N>::P : 1];
+};
+
+template <int LOG2N>
+__device__ __forceinline__ void lds_tw_init(LdsTw<LOG2N>& tw, const float2* __restrict__ twN, int tau) {
+    using C = LdsCfg<LOG2N>;
+#pragma unroll
+    for (int i = 0; i < 16 / C::R0; ++i) {
+        const float2 t = twN[(tau + C::T * i) & (C::N - 1)];
+        tw.w0[i] = cf{t.x, t.y};
+    }
+#pragma unroll
+    for (int p = 1; p < C::P - 1; ++p) {
+        const float2 t = twN[((tau % C::Mp(p)) * (C::N / C::Np(p))) & (C::N - 1)];
+        tw.wp[p] = cf{t.x, t.y};
+    }
+}
+
+// v[i*R0 + j] = x[tau + T (i + C0 j)] on entry (C0 = 16/R0); on return X[tau + T q] is in v[rev16(q)]
+// (for P == 1, i.e. N == 16: X[k] in v[rev16(k)]).  LDS element (inner address a) lives at
+// lds[a * IL + off]: IL = 1 with a per-frame base for frame-per-thread-group use, IL = 16 and
+// off = column for sixteen interleaved columns.  Contains 2 (P-1) workgroup barriers; the first
+// also protects the previous call's last reads.
+template <int LOG2N, int IL>
+__device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ lds, int off, int tau,
+                                             const LdsTw<LOG2N>& tw) {
+    using C = LdsCfg<LOG2N>;
+    constexpr int N = C::N, P = C::P, R0 = C::R0, T = C::T;
+    constexpr int C0 = 16 / R0;
+    if (R0 == 16) {
+        radix16(v);
+    } else {
+#pragma unroll
+        for (int i = 0; i < C0; ++i) small_bfly<R0>(v, i * R0);
+    }
+    if (P > 1) {
+        if (R0 == 16) {
+            cf w[16], w1 = tw.w0[0];
+            asm volatile("" : "+v"(w1.x), "+v"(w1.y));  // keep the tree inside the frame loop (no LICM into 30 VGPRs)
+            pow_tree(w1, w);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < C0; ++i) {
+                cf w1 = tw.w0[i], wk = w1;
+#pragma unroll
+                for (int k = 1; k < R0; ++k) {
+                    v[i * R0 + k] = cmul(v[i * R0 + k], wk);
+                    if (k + 1 < R0) wk = cmul(wk, w1);
+                }
+            }
+        }
+        __syncthreads();  // previous transform's last-pass reads are done
+        constexpr int S1 = C::Mp(0) + C::pad(1);
+#pragma unroll
+        for (int i = 0; i < C0; ++i)
+#pragma unroll
+            for (int k = 0; k < R0; ++k) {
+                const cf z = v[i * R0 + (R0 == 16 ? rev16(k) : k)];
+                lds[((tau + T * i) + S1 * k) * IL + off] = make_float2(z.x, z.y);
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 1; p < P; ++p) {
+        const int Mq = C::Mp(p);
+        const int Sin = C::Mp(p - 1) + C::pad(p);
+        const int Kin = tau / Mq, rr = tau - Kin * Mq;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float2 t = lds[(rr + Mq * j + Sin * Kin) * IL + off];
+            v[j] = cf{t.x, t.y};
+        }
+        radix16(v);
+        if (p < P - 1) {
+            cf w[16], w1 = tw.wp[p];
+            asm volatile("" : "+v"(w1.x), "+v"(w1.y));
+            pow_tree(w1, w);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
+            __syncthreads();  // everyone has read the layout entering pass p
+            const int Sout = Mq + C::pad(p + 1);
+            const int kstep = N / C::Np(p);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const cf z = v[rev16(k)];
+                lds[(rr + Sout * (Kin + kstep * k)) * IL + off] = make_float2(z.x, z.y);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace sdrk

@@ -82,6 +82,8 @@ struct sdrk_plan {
     size_t in_cap = 0;
     void* d_out = nullptr;
     size_t out_cap = 0;
+    float2* d_tw_2p = nullptr;       // two-pass tiled plans (fft_tiled2.hip)
+    bool tiled2 = false;
     bool force_generic = false;      // SDRK_GENERIC=1: use the Stockham radix-2 catch-all kernels (A/B checks)
     // non-power-of-two lengths (bluestein.hip): inner power-of-two plan of size blu_m
     sdrk_plan* blu_inner = nullptr;
@@ -136,6 +138,7 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
     a.d_scratch = p->d_scratch;
     a.scratch_frames = p->scratch_frames;
     a.d_twiddle_big = p->d_tw_big;
+    a.d_twiddle_2p = p->d_tw_2p;
     hipError_t e = hipSuccess;
     if (p->blu_inner) {
         const int N = p->nfft, M = p->blu_m;
@@ -182,7 +185,9 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
                 e = hipMemcpyAsync(p->h_fused_err + 8 * (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl + 1,
                                    8 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
         }
-    } else if (sdrk::fft_tiled_supports(p->nfft))
+    } else if (p->tiled2)
+        e = sdrk::launch_fft_tiled2(a);
+    else if (sdrk::fft_tiled_supports(p->nfft))
         e = sdrk::launch_fft_tiled(a);
     else
         e = sdrk::launch_fft_large(a);
@@ -465,6 +470,24 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
         p->scratch_frames = frames;
         PLAN_TRY(hipMalloc((void**)&p->d_scratch, frames * (size_t)nfft * sizeof(float2)));
     }
+    {
+        int la = 0, lm = 0;
+        const char* t3 = getenv("SDRK_TILED3");   // SDRK_TILED3=1: the older 256 x R x 256 three-pass form (A/B)
+        if (sdrk::fft_tiled2_split(nfft, &la, &lm) && !(t3 && t3[0] == '1') && !p->force_generic) {
+            const int A = 1 << la, M = 1 << lm, TA = A / 16;
+            std::vector<float2> t((size_t)2048 + (size_t)TA * M + (size_t)M * 16);
+            for (int m = 0; m < A; ++m) t[m] = twiddle(m, A);
+            for (int m = 0; m < M; ++m) t[1024 + m] = twiddle(m, M);
+            for (int tau = 0; tau < TA; ++tau)
+                for (int m = 0; m < M; ++m) t[2048 + (size_t)tau * M + m] = twiddle((double)m * tau, (double)nfft);
+            for (int m = 0; m < M; ++m)
+                for (int q = 0; q < 16; ++q)
+                    t[2048 + (size_t)TA * M + (size_t)m * 16 + q] = twiddle((double)m * TA * q, (double)nfft);
+            PLAN_TRY(hipMalloc((void**)&p->d_tw_2p, sizeof(float2) * t.size()));
+            PLAN_TRY(hipMemcpy(p->d_tw_2p, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
+            p->tiled2 = true;
+        }
+    }
     if (nfft == 65536) {
         // Experimental single-launch, XCD-resident form (fft_fused64k.hip): opt in with SDRK_FUSED64K=1.
         // Round-1 measurements: HBM traffic 14-21 B/sample instead of 28, but 1.4x slower than the two tiled
@@ -489,6 +512,7 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->d_window) (void)hipFree(p->d_window);
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_tw_big) (void)hipFree(p->d_tw_big);
+    if (p->d_tw_2p) (void)hipFree(p->d_tw_2p);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->blu_inner) (void)sdrk_plan_destroy(p->blu_inner);
     if (p->d_blu_chirp) (void)hipFree(p->d_blu_chirp);
