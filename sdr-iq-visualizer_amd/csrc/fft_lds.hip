@@ -40,13 +40,19 @@ __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_l
     const size_t n_groups = (n_frames + F - 1) / F;
     const int xor_q = shift ? 8 : 0;
 
-    v2f nxt[16];
+    // Buffer addressing: a wave-uniform descriptor on the group's F frames, clipped to the frames that
+    // exist (lanes of missing frames read zeros and their stores are dropped by the bounds check), one
+    // 32-bit lane offset, uniform steps of T elements.
+    const int lane_in = (int)((size_t)fr * frame_stride + tau) * 8;
+    constexpr int OUT_ELEM = (EPILOGUE == EPI_LOGPSD ? 4 : 8);
+    const int lane_out = (fr * N + tau) * OUT_ELEM;
+    v2u nxt[16];
     auto issue_loads = [&](size_t g) {
-        const size_t f = g * F + fr;
-        const bool ok = f < n_frames;
-        const v2f* __restrict__ x = reinterpret_cast<const v2f*>(iq) + (ok ? f : 0) * frame_stride + tau;
+        const size_t f0 = g * F;
+        const size_t valid = n_frames - f0 < (size_t)F ? n_frames - f0 : (size_t)F;
+        const __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + f0 * frame_stride, (unsigned)(((valid - 1) * frame_stride + N) * 8));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) nxt[q] = ok ? __builtin_nontemporal_load(&x[T * q]) : v2f{0.f, 0.f};
+        for (int q = 0; q < 16; ++q) nxt[q] = __builtin_amdgcn_raw_buffer_load_b64(r, lane_in, q * T * 8, 2);
     };
     if (C::PREFETCH && blockIdx.x < n_groups) issue_loads(blockIdx.x);
 
@@ -57,7 +63,10 @@ __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_l
 #pragma unroll
         for (int i = 0; i < C0; ++i)
 #pragma unroll
-            for (int j = 0; j < R0; ++j) v[i * R0 + j] = cf{nxt[i + C0 * j].x, nxt[i + C0 * j].y};
+            for (int j = 0; j < R0; ++j) {
+                const v2f t = __builtin_bit_cast(v2f, nxt[i + C0 * j]);
+                v[i * R0 + j] = cf{t.x, t.y};
+            }
         if (C::PREFETCH) {
             const size_t gn = g + gridDim.x;
             issue_loads(gn < n_groups ? gn : g);
@@ -70,33 +79,22 @@ __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_l
         }
 
         lds_fft_core<LOG2N, 1>(v, lds, 0, tau, tw);
-        // ---------------- epilogue: X[K + (N/16) q] for K = tau (P > 1) ----------------
-        const size_t f = g * F + fr;
-        if (f < n_frames) {
-            if (P == 1) {
-                // N == 16: the single butterfly's outputs are the spectrum
+        // ---------------- epilogue: X[tau + T q] (for N == 16: X[k]) ----------------
+        {
+            const size_t f0 = g * F;
+            const size_t valid = n_frames - f0 < (size_t)F ? n_frames - f0 : (size_t)F;
+            const __amdgpu_buffer_rsrc_t w = frame_rsrc(static_cast<char*>(out_raw) + f0 * (size_t)N * OUT_ELEM,
+                                                        (unsigned)(valid * N * OUT_ELEM));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const cf z = v[rev16(q)];
+                const int step = (P == 1 ? (q ^ xor_q) : T * (q ^ xor_q)) * OUT_ELEM;
                 if (EPILOGUE == EPI_LOGPSD) {
-                    float* __restrict__ o = static_cast<float*>(out_raw) + f * (size_t)N;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) { cf z = v[rev16(k)]; o[k ^ xor_q] = logpsd_db(z.x, z.y, eps); }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, logpsd_db(z.x, z.y, eps)), w,
+                                                          lane_out, step, 2);
                 } else {
-                    float2* __restrict__ o = static_cast<float2*>(out_raw) + f * (size_t)N;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) { cf z = v[rev16(k)]; o[k ^ xor_q] = make_float2(z.x, z.y); }
-                }
-            } else if (EPILOGUE == EPI_LOGPSD) {
-                float* __restrict__ o = static_cast<float*>(out_raw) + f * (size_t)N + tau;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    cf z = v[rev16(q)];
-                    __builtin_nontemporal_store(logpsd_db(z.x, z.y, eps), &o[T * (q ^ xor_q)]);
-                }
-            } else {
-                float2* __restrict__ o = static_cast<float2*>(out_raw) + f * (size_t)N + tau;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    cf z = v[rev16(q)];
-                    o[T * (q ^ xor_q)] = make_float2(z.x, z.y);
+                    const v2f o = {z.x, z.y};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), w, lane_out, step, 0);
                 }
             }
         }
@@ -137,7 +135,7 @@ static hipError_t launch_lds_n(const LaunchArgs& a) {
     return hipGetLastError();
 }
 
-bool fft_lds_supports(int nfft) { return nfft >= 16 && nfft <= 16384 && (nfft & (nfft - 1)) == 0 && nfft != 4096; }
+bool fft_lds_supports(int nfft) { return nfft >= 16 && nfft <= 16384 && (nfft & (nfft - 1)) == 0; }
 
 hipError_t launch_fft_lds(const LaunchArgs& a) {
     if (a.n_frames == 0) return hipSuccess;
@@ -150,6 +148,7 @@ hipError_t launch_fft_lds(const LaunchArgs& a) {
         case 512: return launch_lds_n<9>(a);
         case 1024: return launch_lds_n<10>(a);
         case 2048: return launch_lds_n<11>(a);
+        case 4096: return launch_lds_n<12>(a);
         case 8192: return launch_lds_n<13>(a);
         case 16384: return launch_lds_n<14>(a);
         default: return hipErrorInvalidValue;

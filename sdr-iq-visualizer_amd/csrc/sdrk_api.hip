@@ -84,6 +84,7 @@ struct sdrk_plan {
     size_t out_cap = 0;
     float2* d_tw_2p = nullptr;       // two-pass tiled plans (fft_tiled2.hip)
     bool tiled2 = false;
+    bool lds4096 = false;            // SDRK_LDS4096=1: run N=4096 through the generic in-LDS kernel (A/B vs fft4096.hip)
     bool force_generic = false;      // SDRK_GENERIC=1: use the Stockham radix-2 catch-all kernels (A/B checks)
     // non-power-of-two lengths (bluestein.hip): inner power-of-two plan of size blu_m
     sdrk_plan* blu_inner = nullptr;
@@ -158,7 +159,7 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
                                       static_cast<char*>(d_out) + f0 * (size_t)N * out_elem, p->num_cus, stream);
             if (e != hipSuccess) break;
         }
-    } else if (p->nfft == 4096)
+    } else if (p->nfft == 4096 && !p->lds4096)
         e = sdrk::launch_fft4096(a);
     else if (sdrk::fft_lds_supports(p->nfft) && !p->force_generic)
         e = sdrk::launch_fft_lds(a);
@@ -437,6 +438,8 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
     {
         const char* genv = getenv("SDRK_GENERIC");
         p->force_generic = genv && genv[0] == '1';
+        const char* l4 = getenv("SDRK_LDS4096");
+        p->lds4096 = l4 && l4[0] == '1';
         // W_N for the in-LDS kernels (N <= 16384); the 4096 table for everything built on fft4096_core.h
         const int tn = (nfft <= 16384 && !(p->force_generic && nfft > 4096)) ? nfft : 4096;
         std::vector<float2> t(tn);
