@@ -118,10 +118,12 @@ static hipError_t launch_lds_n(const LaunchArgs& a) {
 #define SDRK_LDS(W, E)                                                                                        \
     do {                                                                                                      \
         auto kern = fft_lds_kernel<LOG2N, W, E>;                                                              \
-        if (lds_bytes > 64 * 1024) {                                                                          \
+        static bool attr_set = false;   /* per instantiation; idempotent, so a benign race at worst */            \
+        if (lds_bytes > 64 * 1024 && !attr_set) {                                                             \
             hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
             if (e0 != hipSuccess) return e0;                                                                  \
+            attr_set = true;                                                                                  \
         }                                                                                                     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::WG), lds_bytes, a.stream, iq, a.frame_stride, a.d_out,   \
                            a.n_frames, a.d_window, tw, a.eps, a.shift);                                       \

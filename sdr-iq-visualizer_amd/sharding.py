@@ -73,6 +73,37 @@ def spectrum_db_sharded(samples, devices: Sequence[int], *, window=None, eps: fl
     return out
 
 
+def stft_db_sharded(iq, nfft: int, hop: int, devices: Sequence[int], *, window=None, eps: float = 1e-12,
+                    shift: bool = True) -> np.ndarray:
+    """Spectrogram of ONE long stream split by row ranges over ``devices``: device d transforms rows
+    ``[lo, hi)`` from the samples ``[lo*hop, (hi-1)*hop + nfft)`` — its range plus an ``nfft - hop``
+    halo read from the shared host stream, nothing exchanged between devices."""
+    from .spectrum import _as_c64, _cached_plan
+
+    x = _as_c64(iq).reshape(-1)
+    rows = 0 if x.shape[0] < nfft else 1 + (x.shape[0] - nfft) // hop
+    out = np.empty((rows, nfft), dtype=np.float32)
+    errors: List[BaseException] = []
+
+    def work(dev: int, lo: int, hi: int) -> None:
+        try:
+            if hi > lo:
+                seg = x[lo * hop: (hi - 1) * hop + nfft]
+                out[lo:hi] = _cached_plan(nfft, window, eps, shift, dev).stft_db(seg, hop)
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(d, lo, hi))
+               for d, (lo, hi) in zip(devices, shard_ranges(rows, len(devices)))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
 def _default_compute(window, eps, shift, device) -> Callable[[np.ndarray], np.ndarray]:
     from .spectrum import _cached_plan
 

@@ -322,7 +322,14 @@ def welch_psd(iq, nfft: int, sample_rate: float, hop: Optional[int] = None, wind
 
 
 def stft_db(iq, nfft: int, hop: Optional[int] = None, window: WindowArg = None, *, eps: float = 1e-12,
-            shift: bool = True, device: int = 0) -> np.ndarray:
+            shift: bool = True, device: int = 0, devices: Optional[Sequence[int]] = None) -> np.ndarray:
     """Spectrogram rows ``(rows, nfft)`` float32 over one contiguous IQ stream (the
-    waterfall of BASELINE.json config 3: nfft=65536, hop=nfft//2)."""
+    waterfall of BASELINE.json config 3: nfft=65536, hop=nfft//2).  ``devices=[...]`` splits the
+    rows into contiguous ranges, one per GPU, each reading its samples plus an ``nfft-hop`` halo."""
+    if devices is not None and len(devices) > 1:
+        from .sharding import stft_db_sharded
+        return stft_db_sharded(iq, int(nfft), int(nfft if hop is None else hop), devices, window=window, eps=eps,
+                               shift=shift)
+    if devices is not None and len(devices) == 1:
+        device = devices[0]
     return _cached_plan(int(nfft), window, eps, shift, device).stft_db(iq, hop)

@@ -306,6 +306,12 @@ def test_thread_per_device_sharding_single_gpu(pkg):
     out = sharding.spectrum_db_sharded(x, [0, 0])
     assert_db_parity(out, cpu_ref.spectrum_db(x))
     assert np.array_equal(out, pkg.spectrum_db(x, devices=[0]))
+    # one long stream split by row ranges with an nfft-hop halo
+    stream = rand_c64(rng, 4096 * 9 + 123, scale=5.0)
+    whole = pkg.stft_db(stream, 4096, 1024, window="hann")
+    split = pkg.stft_db(stream, 4096, 1024, window="hann", devices=[0, 0, 0])
+    assert split.shape == whole.shape == (1 + (stream.size - 4096) // 1024, 4096)
+    assert np.array_equal(split, whole)
 
 
 # ---- "next" rows on the GPU ------------------------------------------------
