@@ -41,7 +41,7 @@ namespace sdrk {
 // FASTLOG: when every lane of the wave has |X| >= eps * 2^25 on all its 16 bins, |X| + eps rounds to |X|
 // and 20*log10(|X| + eps) = 10*log10(|X|^2): the square root and the add are skipped (wave-uniform branch;
 // any smaller value, zero or NaN in the wave takes the reference-order path).
-template <bool HAS_WINDOW, int EPILOGUE, bool FASTLOG>
+template <bool HAS_WINDOW, int EPILOGUE, bool FASTLOG, bool TWCHAIN>
 __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     const float2* __restrict__ iq, size_t frame_stride, void* __restrict__ out_raw,
     size_t n_frames, const float* __restrict__ window, const float2* __restrict__ tw4096,
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
             for (int j = 0; j < 16; ++j) v[j] = v[j] * lds_win[tid + 256 * j];
 #endif
         }
-        f4k_transform(v, lds, tw256, tw4k, A, tid);
+        f4k_transform<TWCHAIN>(v, lds, tw256, tw4k, A, tid);
         // ---- epilogue + store: bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor) ----
         __amdgpu_buffer_rsrc_t w = frame_rsrc(
             static_cast<char*>(out_raw) + f * (size_t)(F4K_N * OUT_ELEM), F4K_N * OUT_ELEM);
@@ -161,9 +161,15 @@ hipError_t launch_fft4096(const LaunchArgs& a) {
     dim3 g(grid), b(F4K_THREADS);
     const float2* iq = static_cast<const float2*>(a.d_iq);
     const float2* tw = static_cast<const float2*>(a.d_twiddle);
-#define SDRK_LAUNCH(W, E, F)                                                                   \
-    hipLaunchKernelGGL((fft4096_kernel<W, E, F>), g, b, 0, a.stream, iq, a.frame_stride, a.d_out, \
-                       a.n_frames, a.d_window, tw, a.eps, a.shift)
+#define SDRK_LAUNCH(W, E, F)                                                                        \
+    do {                                                                                               \
+        if (a.tw_chain)                                                                                \
+            hipLaunchKernelGGL((fft4096_kernel<W, E, F, true>), g, b, 0, a.stream, iq, a.frame_stride,  \
+                               a.d_out, a.n_frames, a.d_window, tw, a.eps, a.shift);                   \
+        else                                                                                           \
+            hipLaunchKernelGGL((fft4096_kernel<W, E, F, false>), g, b, 0, a.stream, iq, a.frame_stride, \
+                               a.d_out, a.n_frames, a.d_window, tw, a.eps, a.shift);                   \
+    } while (0)
     if (a.epilogue == EPI_LOGPSD) {
         if (a.fast_log) {
             if (a.d_window) SDRK_LAUNCH(true, EPI_LOGPSD, true); else SDRK_LAUNCH(false, EPI_LOGPSD, true);

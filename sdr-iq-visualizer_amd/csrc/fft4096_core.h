@@ -88,27 +88,26 @@ __device__ __forceinline__ void pow_tree(cf w1, cf (&w)[16]) {
 // v[j] = x[tid + 256 j] on entry; on return X[tid + 256 k2] is in v[rev16(k2)].
 // Contains four workgroup barriers; the first one also protects the previous
 // call's exchange-2 reads, so calls may follow each other directly.
+template <bool TWCHAIN = (F4K_TWCHAIN != 0)>
 __device__ __forceinline__ void f4k_transform(cf (&v)[16], float2* __restrict__ lds,
                                               const float2* __restrict__ tw256,
                                               const float2* __restrict__ tw4k, const F4kAddr& A,
                                               int tid) {
     // ---- pass 1: DFT-16 over n2, times W4096^(r k0) = tw4k[k0][n0] * tw256[k0][n1] ----
     radix16(v);
-#if F4K_TWCHAIN
-    {
+    if (TWCHAIN) {
         cf w[16], w1 = A.w1_4096;
         asm volatile("" : "+v"(w1.x), "+v"(w1.y));  // opaque: keep the tree inside the frame loop (no LICM into 30 VGPRs)
         pow_tree(w1, w);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
-    }
-#else
+    } else {
 #pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        float2 wa = tw4k[16 * k + A.lo], wb = tw256[16 * k + A.hi];
-        v[rev16(k)] = cmul(v[rev16(k)], cmul(cf{wa.x, wa.y}, cf{wb.x, wb.y}));
+        for (int k = 1; k < 16; ++k) {
+            float2 wa = tw4k[16 * k + A.lo], wb = tw256[16 * k + A.hi];
+            v[rev16(k)] = cmul(v[rev16(k)], cmul(cf{wa.x, wa.y}, cf{wb.x, wb.y}));
+        }
     }
-#endif
 #if F4K_ABLATE == 1
     radix16(v);
     radix16(v);
@@ -126,21 +125,19 @@ __device__ __forceinline__ void f4k_transform(cf (&v)[16], float2* __restrict__ 
         v[j] = cf{t.x, t.y};
     }
     radix16(v);
-#if F4K_TWCHAIN
-    {
+    if (TWCHAIN) {
         cf w[16], w1 = A.w1_256;
         asm volatile("" : "+v"(w1.x), "+v"(w1.y));
         pow_tree(w1, w);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
-    }
-#else
+    } else {
 #pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        float2 w = tw256[16 * k + A.lo];
-        v[rev16(k)] = cmul(v[rev16(k)], cf{w.x, w.y});
+        for (int k = 1; k < 16; ++k) {
+            float2 w = tw256[16 * k + A.lo];
+            v[rev16(k)] = cmul(v[rev16(k)], cf{w.x, w.y});
+        }
     }
-#endif
     __syncthreads();  // exchange-1 reads are done
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[A.x2w + 16 * k] = make_float2(v[rev16(k)].x, v[rev16(k)].y);

@@ -75,10 +75,10 @@ int main(int argc, char** argv) {
     sdrk::LaunchArgs a; a.d_iq = d_in; a.frame_stride = 4096; a.d_out = d_out; a.n_frames = nf; a.nfft = 4096;
     a.d_window = win ? d_win : nullptr; a.d_twiddle = d_tw; a.stream = s; a.num_cus = prop.multiProcessorCount;
     for (int round = 0; round < 3; ++round) {   // interleaved A/B on the same buffers
-        a.fast_log = false;
-        time_it("fft4096 reference-order log", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
-        a.fast_log = true;
-        time_it("fft4096 fast log", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+        a.fast_log = false; a.tw_chain = false;
+        time_it("fft4096 table twiddles", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+        a.tw_chain = true;
+        time_it("fft4096 product-tree twiddles", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
     }
     if (argc > 4) {   // placement experiment: same kernel, output (or input) buffer shifted / re-allocated
         for (size_t off : {(size_t)4096, (size_t)65536, (size_t)1 << 20, (size_t)3 << 20, (size_t)64 << 20}) {

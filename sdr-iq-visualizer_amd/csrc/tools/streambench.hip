@@ -63,6 +63,21 @@ __global__ __launch_bounds__(256) void tdma_k(const v4f* __restrict__ in, v4f* _
     }
 }
 
+// cache-policy sweep with buffer instructions: LD_AUX / ST_AUX = sc0 (1) | nt (2) | sc1 (16)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template <int LD_AUX, int ST_AUX>
+__global__ __launch_bounds__(256) void policy_k(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n_frames) {
+    for (size_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(in + f * 2048), 0, 32768, 0x00020000);
+        __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc((void*)(out + f * 1024), 0, 16384, 0x00020000);
+        v4u v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, threadIdx.x * 16, j * 4096, LD_AUX);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[2 * j] ^ v[2 * j + 1], w, threadIdx.x * 16, j * 4096, ST_AUX);
+    }
+}
+
 // classic copy: n float4 in -> n float4 out, grid-stride
 template <int NT>
 __global__ __launch_bounds__(256) void copy_k(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n) {
@@ -115,6 +130,16 @@ int main(int argc, char** argv) {
         for (auto tr_tw : {std::pair<unsigned, unsigned>{175, 110}, {350, 220}, {700, 440}, {1400, 880}, {350, 350}, {240, 240}}) {
             float t = time_it(reps, s, [&] { hipLaunchKernelGGL(tdma_k, dim3(g), dim3(256), 0, s, in, out, nf, tr_tw.first, tr_tw.second); });
             printf("bpc %d  TDMA TR=%4u TW=%4u (x10 ns)   %8.3f ms %7.1f GB/s\n", bpc, tr_tw.first, tr_tw.second, t, rw / t / 1e6);
+        }
+    }
+    {
+        unsigned g = cus * 3;
+        double rw = 12.0 * nf * 4096;
+        float t;
+#define POL(L, S) t = time_it(reps, s, [&] { hipLaunchKernelGGL((policy_k<L, S>), dim3(g), dim3(256), 0, s, in, out, nf); }); \
+        printf("bpc 3 policy ld_aux=%2d st_aux=%2d   %8.3f ms %7.1f GB/s\n", L, S, t, rw / t / 1e6);
+        for (int rep = 0; rep < 2; ++rep) {
+            POL(2, 2) POL(0, 0) POL(2, 0) POL(0, 2) POL(2, 16) POL(2, 18) POL(2, 17) POL(2, 19) POL(16, 2) POL(18, 2) POL(1, 2) POL(2, 1) POL(2, 3)
         }
     }
     size_t n4 = nf * 2048;  // float4 count of the input

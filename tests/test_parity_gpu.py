@@ -534,3 +534,27 @@ def test_non_power_of_two_lengths_via_bluestein(pkg, n):
         assert int(np.argmax(pkg.spectrum_db(tone))) == (n // 2 + 2) % n
         rows = pkg.stft_db(np.tile(x[0], 3), n, max(1, n // 3))
         assert_db_parity(rows, cpu_ref.stft_db(np.tile(x[0], 3), n, max(1, n // 3)), what=f"stft n={n}")
+
+
+def test_edge_cases_errors_and_special_values(pkg):
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    with pytest.raises(pkg.SdrkError):
+        SpectrumPlan(4096, device=99)                                  # no such GPU: loud, no fallback
+    with pytest.raises(ValueError):
+        SpectrumPlan(4096, eps=-1.0)
+    # a NaN anywhere in a frame poisons that frame's row (every bin depends on every sample) and only that row
+    x = rand_c64(np.random.default_rng(0), 3, 4096)
+    x[1, 77] = np.nan
+    got = pkg.spectrum_db(x)
+    assert np.isnan(got[1]).all() and np.isfinite(got[0]).all() and np.isfinite(got[2]).all()
+    assert np.isnan(cpu_ref.spectrum_db(x)[1]).all()                   # as numpy does
+    # eps = 0 on an exactly-zero bin gives -inf like the reference's legacy script (pyad-iio-test.py:61)
+    z = pkg.spectrum_db(np.zeros(4096, dtype=np.complex64), eps=0.0)
+    assert np.isneginf(z).all()
+    # waterfall of depth 1 keeps only the newest row
+    wf = pkg.WaterfallBuffer(1000, maxlen=1)                           # non-power-of-two rows are fine too
+    rows = np.arange(3000, dtype=np.float32).reshape(3, 1000)
+    wf.append(rows)
+    assert len(wf) == 1 and np.array_equal(wf.as_array()[0], rows[2])
+    wf.append_iq(rand_c64(np.random.default_rng(1), 2, 1000))
+    assert wf.as_array().shape == (1, 1000)
