@@ -84,6 +84,9 @@ __device__ __forceinline__ Poll3 wg_poll3(const unsigned* p0, unsigned w0, const
             }
             v = ld_agent(p);
         }
+#ifdef FU_STATS
+        if (spins) atomicAdd(err + 8 + tid, spins);      // record[8..10]: spins on cur / prev chunk words
+#endif
         sh[tid] = v;
     }
     __syncthreads();
@@ -94,7 +97,8 @@ __device__ __forceinline__ Poll3 wg_poll3(const unsigned* p0, unsigned w0, const
 }
 
 // Thread 0 spins until *p >= want; workgroup-uniform result (FU_POISON on timeout / error).
-__device__ __forceinline__ unsigned wg_wait_count(const unsigned* p, unsigned want, unsigned* err, unsigned* sh) {
+__device__ __forceinline__ unsigned wg_wait_count(const unsigned* p, unsigned want, unsigned* err, unsigned* sh,
+                                                  int site = 1) {
     if (threadIdx.x == 0) {
         unsigned v = ld_agent(p), spins = 0;
         while (v < want) {
@@ -109,6 +113,10 @@ __device__ __forceinline__ unsigned wg_wait_count(const unsigned* p, unsigned wa
             }
             v = ld_agent(p);
         }
+#ifdef FU_STATS
+        if (spins) atomicAdd(err + 11 + site, spins);   // record[12]: K1 ring-slot wait spins, record[13]: K3 done1 wait spins
+        atomicAdd(err + 13 + site, 1u);      // record[14], [15]: how many such waits
+#endif
         sh[0] = v;
     }
     __syncthreads();
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
             }
             radix16(v);
             // the ring slot must have been drained by the K3 tiles of slot s - S (usually long ago)
-            if (!dep_ready && wg_wait_count(dep, 16, err, sh_u) == FU_POISON) break;
+            if (!dep_ready && wg_wait_count(dep, 16, err, sh_u, 1) == FU_POISON) break;
             float2* __restrict__ o = my_ring + (size_t)(s % FU_RING_SLOTS) * FU_N + m;
             const float2 bw = t1[m * 16 + hi];
             const cf base = cf{bw.x, bw.y};
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
         } else {
             // ---------------- K3: row tile `sub-16` of frame prev-1 <- ring slot (s-1) % S ----------------
             if (prev == FU_END) continue;
-            if (!dep_ready && wg_wait_count(dep, 16, err, sh_u) == FU_POISON) break;
+            if (!dep_ready && wg_wait_count(dep, 16, err, sh_u, 2) == FU_POISON) break;
             const size_t f = prev - 1;
             const int k3_0 = (int)(sub - 16) * 16;
             const unsigned long long* __restrict__ in = reinterpret_cast<const unsigned long long*>(

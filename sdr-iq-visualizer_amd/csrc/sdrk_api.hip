@@ -183,8 +183,8 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
             }
             e = sdrk::launch_fused64k(b, p->d_fused_ring, p->d_fused_ctrl, p->fused_ctrl_words);
             if (e == hipSuccess)
-                e = hipMemcpyAsync(p->h_fused_err + 8 * (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl + 1,
-                                   8 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+                e = hipMemcpyAsync(p->h_fused_err + 16 * (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl + 1,
+                                   16 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
         }
     } else if (p->tiled2)
         e = sdrk::launch_fft_tiled2(a);
@@ -199,11 +199,18 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
 // After a stream sync: did any fused N=65536 launch report an internal wait timeout?
 int fused_check(sdrk_plan* p) {
     if (!p->fused64k || !p->h_fused_err) return SDRK_OK;
-    unsigned bad = 0, rec[8] = {0};
+    unsigned bad = 0, rec[16] = {0};
+#ifdef FU_STATS
+    if (p->fused_launches) {
+        const unsigned* r = p->h_fused_err + 16 * ((p->fused_launches - 1) % FUSED_MAILBOX);
+        fprintf(stderr, "[fused64k stats] spins: cur-chunk %u prev-chunk %u | K1 ring wait %u spins in %u waits | "
+                "K3 done1 wait %u spins in %u waits\n", r[8], r[9], r[12], r[14], r[13], r[15]);
+    }
+#endif
     for (unsigned i = 0; i < FUSED_MAILBOX; ++i) {
-        if (p->h_fused_err[8 * i] && !bad) memcpy(rec, p->h_fused_err + 8 * i, sizeof rec);
-        bad |= p->h_fused_err[8 * i];
-        memset(p->h_fused_err + 8 * i, 0, 8 * sizeof(unsigned));
+        if (p->h_fused_err[16 * i] && !bad) memcpy(rec, p->h_fused_err + 16 * i, sizeof rec);
+        bad |= p->h_fused_err[16 * i];
+        memset(p->h_fused_err + 16 * i, 0, 16 * sizeof(unsigned));
     }
     if (bad)
         return fail(SDRK_ERR_HIP, "fused N=65536 kernel reported an internal synchronisation error (code %u; word %u held %u, "
@@ -499,8 +506,8 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
         p->fused64k = env && env[0] == '1';
         if (p->fused64k) {
             PLAN_TRY(hipMalloc(&p->d_fused_ring, sdrk::fused64k_ring_bytes()));
-            PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * 8 * sizeof(unsigned), hipHostMallocDefault));
-            memset(p->h_fused_err, 0, FUSED_MAILBOX * 8 * sizeof(unsigned));
+            PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * 16 * sizeof(unsigned), hipHostMallocDefault));
+            memset(p->h_fused_err, 0, FUSED_MAILBOX * 16 * sizeof(unsigned));
         }
     }
 #undef PLAN_TRY
