@@ -13,6 +13,12 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The suite binds sdr-iq-visualizer_amd/lib/libsdrk.so; build it if the tree is fresh (hipcc
+    # cross-compiles gfx950 without a GPU).  __graft_entry__.build() does the same.
+    lib = os.path.join(REPO, "sdr-iq-visualizer_amd", "lib", "libsdrk.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(REPO, "sdr-iq-visualizer_amd", "csrc"), "-j", "8"], check=False)
 
 
 @pytest.fixture(scope="session")
