@@ -558,3 +558,36 @@ def test_edge_cases_errors_and_special_values(pkg):
     assert len(wf) == 1 and np.array_equal(wf.as_array()[0], rows[2])
     wf.append_iq(rand_c64(np.random.default_rng(1), 2, 1000))
     assert wf.as_array().shape == (1, 1000)
+
+
+def test_config3_full_size_sampled_rows(pkg):
+    """BASELINE.json config 3 at full size: 10 s @ 61.44 Msps = 614 400 000 samples on the device,
+    N = 65536, hop = 32768, Hann -> 18 749 rows (9.8 GB through the kernels); rows sampled across the run
+    (first, last, around chunk boundaries) against the oracle on the numpy-regenerated samples."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, synth
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    L, n, hop = 614_400_000, 65536, 32768
+    rows = 1 + (L - n) // hop
+    assert rows == 18749
+    gen_frames = (L + 4095) // 4096                       # the stream = consecutive 4096-sample generator frames
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, gen_frames * 4096 * 8, ctypes.byref(d_in)))
+    _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_out)))
+    try:
+        _ffi.check(lib.sdrk_synth_fill(0, 31, 0, gen_frames, 4096, d_in, None))
+        with SpectrumPlan(n, window="hann") as plan:
+            plan.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)
+            plan.sync()
+        w = np.hanning(n)
+        row = np.empty(n, dtype=np.float32)
+        for r in (0, 1, 255, 256, 257, 9000, 18747, 18748):
+            _ffi.check(lib.sdrk_memcpy_d2h(0, row.ctypes.data_as(ctypes.c_void_p),
+                                           ctypes.c_void_p(d_out.value + r * n * 4), row.nbytes))
+            first = (r * hop) // 4096                      # generator frames covering samples [r*hop, r*hop + n)
+            x = synth.synth_iq(31, first, n // 4096 + 1, 4096).reshape(-1)[(r * hop) % 4096:][:n]
+            assert_db_parity(row, cpu_ref.spectrum_db(x, window=w), what=f"row {r}")
+    finally:
+        lib.sdrk_dev_free(0, d_in)
+        lib.sdrk_dev_free(0, d_out)
