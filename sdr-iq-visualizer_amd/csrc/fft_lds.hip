@@ -141,6 +141,10 @@ bool fft_lds_supports(int nfft) { return nfft >= 16 && nfft <= 16384 && (nfft & 
 
 hipError_t launch_fft_lds(const LaunchArgs& a) {
     if (a.n_frames == 0) return hipSuccess;
+    // Frames of one workgroup share a buffer descriptor with 32-bit lane offsets: absurdly spaced frames
+    // (group span >= 2 GiB) go to the pointer-addressed catch-all instead.
+    if (a.nfft < 4096 && ((size_t)(4096 / a.nfft) * a.frame_stride + (size_t)a.nfft) * 8 >= ((size_t)1 << 31))
+        return launch_fft_small(a);
     switch (a.nfft) {
         case 16: return launch_lds_n<4>(a);
         case 32: return launch_lds_n<5>(a);
