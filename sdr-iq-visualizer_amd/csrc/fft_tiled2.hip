@@ -18,25 +18,30 @@
 
 namespace sdrk {
 
-template <int LOG2A, bool HAS_WINDOW>
-__global__ __launch_bounds__(LdsCfg<LOG2A>::N, (LdsCfg<LOG2A>::N >= 512 ? 4 : 3)) void col_pass_kernel(
+// W = tile width in columns (16, or 8 for A = 1024 so that two 512-thread workgroups fit a CU)
+template <int LOG2A, bool HAS_WINDOW, int W>
+__global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 ? 4 : 3)) void col_pass_kernel(
     const float2* __restrict__ iq, size_t frame_stride, float2* __restrict__ scratch, size_t n_frames, int M,
     const float* __restrict__ window, const float2* __restrict__ twA, const float2* __restrict__ t1T,
     const float2* __restrict__ t2) {
     using C = LdsCfg<LOG2A>;
     constexpr int A = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0;
-    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 17 A elements: 16 interleaved columns
+    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 17/16 A W elements: W interleaved columns
     const int tid = threadIdx.x;
-    const int fr = tid & 15, tau = tid >> 4;
+    const int fr = tid & (W - 1), tau = tid / W;
     LdsTw<LOG2A> tw;
     lds_tw_init<LOG2A>(tw, twA, tau);
     const size_t nfft = (size_t)A * M;
-    const int tiles = M / 16;
+    const int tiles = M / W;
     const size_t items = n_frames * (size_t)tiles;
 
-    for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
+    for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
+        // W == 8: the two tiles that share each 128-byte line go to blocks b and b+8 (same XCD under the
+        // round-robin placement; a speed hint only)
+        size_t it = g;
+        if (W == 8 && (items & 15) == 0) it = (g & ~(size_t)15) + ((g & 7) << 1) + ((g >> 3) & 1);
         const size_t f = it / tiles;
-        const int m = (int)(it - f * tiles) * 16 + fr;
+        const int m = (int)(it - f * tiles) * W + fr;
         // buffer addressing: wave-uniform descriptor on the frame, one 32-bit lane offset, uniform row steps
         const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + f * frame_stride, (unsigned)(nfft * 8));
         const __amdgpu_buffer_rsrc_t rw = frame_rsrc(window, HAS_WINDOW ? (unsigned)(nfft * 4) : 0u);
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::N, (LdsCfg<LOG2A>::N >= 512 ? 4 : 3)
                 }
                 v[i * R0 + j] = cf{t.x, t.y};
             }
-        lds_fft_core<LOG2A, 16>(v, lds_all, fr, tau, tw);
+        lds_fft_core<LOG2A, W>(v, lds_all, fr, tau, tw);
         // B[k3 = tau + T q] * W_N^(m k3),  W_N^(m k3) = W_N^(m tau) * W_N^(m T q)
         const __amdgpu_buffer_rsrc_t ro = frame_rsrc(scratch + f * nfft, (unsigned)(nfft * 8));
         const float2 bw = t1T[e0];
@@ -73,6 +78,11 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::N, (LdsCfg<LOG2A>::N >= 512 ? 4 : 3)
         }
     }
 }
+
+#ifndef SDRK_COL_W1024
+#define SDRK_COL_W1024 16   // 8 (two 512-thread workgroups per CU, 64-byte segments) measured 10 % slower at N = 2^20
+#endif
+#define COL_TILE_W(LOG2A) ((LOG2A) == 10 ? SDRK_COL_W1024 : 16)
 
 template <int LOG2M, int EPILOGUE>
 __global__ __launch_bounds__(LdsCfg<LOG2M>::N, (LdsCfg<LOG2M>::N >= 512 ? 4 : 3)) void row_pass_kernel(
@@ -157,16 +167,19 @@ bool fft_tiled2_split(int nfft, int* log2a, int* log2m) {
 template <int LOG2A>
 static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, int M, unsigned grid_cap) {
     using C = LdsCfg<LOG2A>;
-    const size_t lds_bytes = (size_t)17 * C::N * sizeof(float2);
-    const size_t items = nf * (size_t)(M / 16);
-    const unsigned grid = (unsigned)(items < grid_cap ? items : grid_cap);
+    constexpr int W = COL_TILE_W(LOG2A);
+    const size_t lds_bytes = (size_t)(C::SLOT) * W * sizeof(float2);
+    const size_t items = nf * (size_t)(M / W);
+    if (W == 8) grid_cap = (unsigned)a.num_cus * 2;
+    unsigned grid = (unsigned)(items < grid_cap ? items : grid_cap);
+    if (W == 8 && grid >= 16) grid &= ~15u;
     const float2* twA = static_cast<const float2*>(a.d_twiddle_2p);
     const float2* t1T = twA + 1024 + 1024;
     const float2* t2 = t1T + (size_t)(C::T) * M;
     float2* scratch = static_cast<float2*>(a.d_scratch);
-#define SDRK_COL(W)                                                                                              \
+#define SDRK_COL(WIN)                                                                                            \
     do {                                                                                                         \
-        auto kern = col_pass_kernel<LOG2A, W>;                                                                   \
+        auto kern = col_pass_kernel<LOG2A, WIN, W>;                                                              \
         static bool attr_set = false;   /* per instantiation; idempotent, so a benign race at worst */               \
         if (lds_bytes > 64 * 1024 && !attr_set) {                                                                \
             hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
@@ -174,8 +187,8 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
             if (e0 != hipSuccess) return e0;                                                                     \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::N), lds_bytes, a.stream, src, a.frame_stride, scratch, nf, M, \
-                           a.d_window, twA, t1T, t2);                                                            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * W), lds_bytes, a.stream, src, a.frame_stride, scratch, nf, \
+                           M, a.d_window, twA, t1T, t2);                                                            \
     } while (0)
     if (a.d_window) SDRK_COL(true); else SDRK_COL(false);
 #undef SDRK_COL
