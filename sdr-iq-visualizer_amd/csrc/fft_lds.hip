@@ -21,7 +21,11 @@
 
 namespace sdrk {
 
-template <int LOG2N, bool HAS_WINDOW, int EPILOGUE>
+// STAGED (N <= 64, packed frames only): with fewer than 8 threads per frame the per-thread pattern
+// x[tau + T q] touches 64 different 128-byte lines per wave instruction, so the group's 4096 contiguous
+// samples are loaded lane-contiguously, parked in LDS (padded by one element per 16) and picked up from
+// there; the rows take the same route out.
+template <int LOG2N, bool HAS_WINDOW, int EPILOGUE, bool STAGED>
 __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_lds_kernel(
     const float2* __restrict__ iq, size_t frame_stride, void* __restrict__ out_raw, size_t n_frames,
     const float* __restrict__ window, const float2* __restrict__ twN /* W_N^m, m < N */, float eps, int shift) {
@@ -43,30 +47,53 @@ __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_l
     // Buffer addressing: a wave-uniform descriptor on the group's F frames, clipped to the frames that
     // exist (lanes of missing frames read zeros and their stores are dropped by the bounds check), one
     // 32-bit lane offset, uniform steps of T elements.
-    const int lane_in = (int)((size_t)fr * frame_stride + tau) * 8;
+    const int lane_in = STAGED ? tid * 8 : (int)((size_t)fr * frame_stride + tau) * 8;
     constexpr int OUT_ELEM = (EPILOGUE == EPI_LOGPSD ? 4 : 8);
-    const int lane_out = (fr * N + tau) * OUT_ELEM;
+    const int lane_out = STAGED ? tid * OUT_ELEM : (fr * N + tau) * OUT_ELEM;
+    constexpr int IN_STEP = STAGED ? 256 : T;   // elements between a thread's consecutive loads
     v2u nxt[16];
     auto issue_loads = [&](size_t g) {
         const size_t f0 = g * F;
         const size_t valid = n_frames - f0 < (size_t)F ? n_frames - f0 : (size_t)F;
         const __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + f0 * frame_stride, (unsigned)(((valid - 1) * frame_stride + N) * 8));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) nxt[q] = __builtin_amdgcn_raw_buffer_load_b64(r, lane_in, q * T * 8, 2);
+        for (int q = 0; q < 16; ++q) nxt[q] = __builtin_amdgcn_raw_buffer_load_b64(r, lane_in, q * IN_STEP * 8, 2);
     };
     if (C::PREFETCH && blockIdx.x < n_groups) issue_loads(blockIdx.x);
 
     for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         if (!C::PREFETCH) issue_loads(g);
         cf v[16];
-        // register i*R0 + j <- sample n = tau + T i + M_0 j = tau + T (i + C0 j)
+        if constexpr (STAGED) {
+            // park element e = tid + 256 q of the group (frame e / N, sample e % N) ...
+            __syncthreads();   // the previous group's staged rows have been read back
 #pragma unroll
-        for (int i = 0; i < C0; ++i)
-#pragma unroll
-            for (int j = 0; j < R0; ++j) {
-                const v2f t = __builtin_bit_cast(v2f, nxt[i + C0 * j]);
-                v[i * R0 + j] = cf{t.x, t.y};
+            for (int q = 0; q < 16; ++q) {
+                const int e = tid + 256 * q, fe = e / N, n = e - fe * N;
+                const v2f t = __builtin_bit_cast(v2f, nxt[q]);
+                lds_all[fe * C::SLOT + n + (n >> 4)] = make_float2(t.x, t.y);
             }
+            __syncthreads();
+            // ... and pick up register i*R0 + j <- sample n = tau + T (i + C0 j) of this thread's frame
+#pragma unroll
+            for (int i = 0; i < C0; ++i)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int n = tau + T * (i + C0 * j);
+                    const float2 t = lds[n + (n >> 4)];
+                    v[i * R0 + j] = cf{t.x, t.y};
+                }
+            if (P == 1) __syncthreads();   // (for P > 1 the transform's first barrier covers these reads)
+        } else {
+            // register i*R0 + j <- sample n = tau + T i + M_0 j = tau + T (i + C0 j)
+#pragma unroll
+            for (int i = 0; i < C0; ++i)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const v2f t = __builtin_bit_cast(v2f, nxt[i + C0 * j]);
+                    v[i * R0 + j] = cf{t.x, t.y};
+                }
+        }
         if (C::PREFETCH) {
             const size_t gn = g + gridDim.x;
             issue_loads(gn < n_groups ? gn : g);
@@ -80,7 +107,45 @@ __global__ __launch_bounds__(LdsCfg<LOG2N>::WG, LdsCfg<LOG2N>::WAVES) void fft_l
 
         lds_fft_core<LOG2N, 1>(v, lds, 0, tau, tw);
         // ---------------- epilogue: X[tau + T q] (for N == 16: X[k]) ----------------
-        {
+        if constexpr (STAGED) {
+            const size_t f0 = g * F;
+            const size_t valid = n_frames - f0 < (size_t)F ? n_frames - f0 : (size_t)F;
+            const __amdgpu_buffer_rsrc_t w = frame_rsrc(static_cast<char*>(out_raw) + f0 * (size_t)N * OUT_ELEM,
+                                                        (unsigned)(valid * N * OUT_ELEM));
+            __syncthreads();   // every thread is through its last exchange reads: LDS becomes the row staging area
+            if (EPILOGUE == EPI_LOGPSD) {
+                float* __restrict__ st = reinterpret_cast<float*>(lds_all);   // frame fe at fe * (N + 1)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const cf z = v[rev16(q)];
+                    const int k = P == 1 ? (q ^ xor_q) : tau + T * (q ^ xor_q);
+                    st[fr * (N + 1) + k] = logpsd_db(z.x, z.y, eps);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int e = tid + 256 * q, fe = e / N, k = e - fe * N;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st[fe * (N + 1) + k]), w, lane_out,
+                                                          q * 256 * OUT_ELEM, 2);
+                }
+            } else {
+                float2* __restrict__ st = lds_all;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const cf z = v[rev16(q)];
+                    const int k = P == 1 ? (q ^ xor_q) : tau + T * (q ^ xor_q);
+                    st[fr * (N + 1) + k] = make_float2(z.x, z.y);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int e = tid + 256 * q, fe = e / N, k = e - fe * N;
+                    const float2 t = st[fe * (N + 1) + k];
+                    const v2f o = {t.x, t.y};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), w, lane_out, q * 256 * OUT_ELEM, 0);
+                }
+            }
+        } else {
             const size_t f0 = g * F;
             const size_t valid = n_frames - f0 < (size_t)F ? n_frames - f0 : (size_t)F;
             const __amdgpu_buffer_rsrc_t w = frame_rsrc(static_cast<char*>(out_raw) + f0 * (size_t)N * OUT_ELEM,
@@ -115,9 +180,11 @@ static hipError_t launch_lds_n(const LaunchArgs& a) {
     const unsigned grid = (unsigned)(n_groups < max_blocks ? n_groups : max_blocks);
     const float2* iq = static_cast<const float2*>(a.d_iq);
     const float2* tw = static_cast<const float2*>(a.d_twiddle);
+    const bool staged = LOG2N <= 7 && a.frame_stride == (size_t)C::N;
 #define SDRK_LDS(W, E)                                                                                        \
     do {                                                                                                      \
-        auto kern = fft_lds_kernel<LOG2N, W, E>;                                                              \
+        auto kern = (LOG2N <= 7 && staged) ? fft_lds_kernel<LOG2N, W, E, (LOG2N <= 7)>                        \
+                                            : fft_lds_kernel<LOG2N, W, E, false>;                             \
         static bool attr_set = false;   /* per instantiation; idempotent, so a benign race at worst */            \
         if (lds_bytes > 64 * 1024 && !attr_set) {                                                             \
             hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
