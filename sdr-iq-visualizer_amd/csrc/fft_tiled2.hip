@@ -82,10 +82,12 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
 #ifndef SDRK_COL_W1024
 #define SDRK_COL_W1024 16   // 8 (two 512-thread workgroups per CU, 64-byte segments) measured 10 % slower at N = 2^20
 #endif
-#define COL_TILE_W(LOG2A) ((LOG2A) == 10 ? SDRK_COL_W1024 : 16)
+#define COL_TILE_W(LOG2A) ((LOG2A) == 11 ? 8 : ((LOG2A) == 10 ? SDRK_COL_W1024 : 16))
+#define ROW_TILE_R(LOG2M) ((LOG2M) == 11 ? 8 : 16)
 
-template <int LOG2M, int EPILOGUE>
-__global__ __launch_bounds__(LdsCfg<LOG2M>::N, (LdsCfg<LOG2M>::N >= 512 ? 4 : 3)) void row_pass_kernel(
+// ROWS = rows per tile (16, or 8 for M = 2048 so that the tile fits the LDS)
+template <int LOG2M, int EPILOGUE, int ROWS>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS, (LdsCfg<LOG2M>::T * ROWS >= 512 ? 4 : 3)) void row_pass_kernel(
     const float2* __restrict__ scratch, void* __restrict__ out_raw, size_t n_frames, int A,
     const float2* __restrict__ twM, float eps, int shift) {
     using C = LdsCfg<LOG2M>;
@@ -97,14 +99,15 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::N, (LdsCfg<LOG2M>::N >= 512 ? 4 : 3)
     LdsTw<LOG2M> tw;
     lds_tw_init<LOG2M>(tw, twM, tau);
     const size_t nfft = (size_t)A * M;
-    const int tiles = A / 16;
+    const int tiles = A / ROWS;
     const size_t items = n_frames * (size_t)tiles;
     const int xor_q = shift ? 8 : 0;
+    constexpr int WGT = T * ROWS;   // threads
 
     for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
         const size_t f = it / tiles;
-        const int k3_0 = (int)(it - f * tiles) * 16;
-        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)k3_0 * M, (unsigned)(16 * M * 8));
+        const int k3_0 = (int)(it - f * tiles) * ROWS;
+        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)k3_0 * M, (unsigned)(ROWS * M * 8));
         const int e0 = fr * M + tau;
         cf v[16];
 #pragma unroll
@@ -117,37 +120,37 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::N, (LdsCfg<LOG2M>::N >= 512 ? 4 : 3)
         lds_fft_core<LOG2M, 1>(v, lds, 0, tau, tw);
         __syncthreads();  // all rows are through their last LDS reads: the buffer becomes the transpose tile
         if (EPILOGUE == EPI_LOGPSD) {
-            float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][17]
+            float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][ROWS + 1]
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf z = v[rev16(q)];
-                tile[(tau + T * (q ^ xor_q)) * 17 + fr] = logpsd_db(z.x, z.y, eps);
+                tile[(tau + T * (q ^ xor_q)) * (ROWS + 1) + fr] = logpsd_db(z.x, z.y, eps);
             }
             __syncthreads();
             const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float*>(out_raw) + f * nfft + k3_0,
                                                          (unsigned)((nfft - k3_0) * 4));
-            // element e = tid + M i of the 16 x M tile: row r = e & 15 (lanes), km = e >> 4 = (tid >> 4) + (M/16) i
-            const int r = tid & 15, km0 = tid >> 4;
+            // element e = tid + WGT i of the ROWS x M tile: row r = e % ROWS (lanes), km = e / ROWS = tid / ROWS + T i
+            const int r = tid & (ROWS - 1), km0 = tid / ROWS;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float val = tile[(km0 + T * i) * 17 + r];
+                const float val = tile[(km0 + T * i) * (ROWS + 1) + r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, (km0 * A + r) * 4,
                                                       i * T * A * 4, 2);
             }
         } else {
-            float2* __restrict__ tile = lds_all;  // [km][17]
+            float2* __restrict__ tile = lds_all;  // [km][ROWS + 1]
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf z = v[rev16(q)];
-                tile[(tau + T * (q ^ xor_q)) * 17 + fr] = make_float2(z.x, z.y);
+                tile[(tau + T * (q ^ xor_q)) * (ROWS + 1) + fr] = make_float2(z.x, z.y);
             }
             __syncthreads();
             float2* __restrict__ o = static_cast<float2*>(out_raw) + f * nfft + k3_0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int e = tid + M * i;
-                const int r = e & 15, km = e >> 4;
-                o[(size_t)km * A + r] = tile[km * 17 + r];
+                const int e = tid + WGT * i;
+                const int r = e & (ROWS - 1), km = e / ROWS;
+                o[(size_t)km * A + r] = tile[km * (ROWS + 1) + r];
             }
         }
         __syncthreads();  // tile reads done before the next item's exchanges
@@ -157,8 +160,8 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::N, (LdsCfg<LOG2M>::N >= 512 ? 4 : 3)
 bool fft_tiled2_split(int nfft, int* log2a, int* log2m) {
     int lg = 0;
     while ((1 << lg) < nfft) ++lg;
-    if ((1 << lg) != nfft || lg < 15 || lg > 20) return false;
-    const int la = lg / 2 < 7 ? 7 : lg / 2;   // 2^15 -> 128 x 256 ; 2^17 -> 256 x 512 ; 2^20 -> 1024 x 1024
+    if ((1 << lg) != nfft || lg < 15 || lg > 22) return false;
+    const int la = lg / 2 < 7 ? 7 : lg / 2;   // 2^15 -> 128 x 256 ; 2^17 -> 256 x 512 ; 2^20 -> 1024 x 1024 ; 2^22 -> 2048 x 2048
     *log2a = la;
     *log2m = lg - la;
     return true;
@@ -174,7 +177,7 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
     unsigned grid = (unsigned)(items < grid_cap ? items : grid_cap);
     if (W == 8 && grid >= 16) grid &= ~15u;
     const float2* twA = static_cast<const float2*>(a.d_twiddle_2p);
-    const float2* t1T = twA + 1024 + 1024;
+    const float2* t1T = twA + 2048 + 2048;
     const float2* t2 = t1T + (size_t)(C::T) * M;
     float2* scratch = static_cast<float2*>(a.d_scratch);
 #define SDRK_COL(WIN)                                                                                            \
@@ -198,14 +201,17 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
 template <int LOG2M>
 static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, unsigned grid_cap) {
     using C = LdsCfg<LOG2M>;
-    const size_t lds_bytes = (size_t)17 * C::N * sizeof(float2);
-    const size_t items = nf * (size_t)(A / 16);
+    constexpr int ROWS = ROW_TILE_R(LOG2M);
+    // LDS: the exchange area (ROWS x 17/16 M complex) or the complex transpose tile (M x (ROWS+1)), whichever is larger
+    const size_t xch = (size_t)ROWS * C::SLOT, tile = (size_t)C::N * (ROWS + 1);
+    const size_t lds_bytes = (xch > tile ? xch : tile) * sizeof(float2);
+    const size_t items = nf * (size_t)(A / ROWS);
     const unsigned grid = (unsigned)(items < grid_cap ? items : grid_cap);
-    const float2* twM = static_cast<const float2*>(a.d_twiddle_2p) + 1024;
+    const float2* twM = static_cast<const float2*>(a.d_twiddle_2p) + 2048;
     const float2* scratch = static_cast<const float2*>(a.d_scratch);
 #define SDRK_ROW(E)                                                                                              \
     do {                                                                                                         \
-        auto kern = row_pass_kernel<LOG2M, E>;                                                                   \
+        auto kern = row_pass_kernel<LOG2M, E, ROWS>;                                                                   \
         static bool attr_set = false;   /* per instantiation; idempotent, so a benign race at worst */               \
         if (lds_bytes > 64 * 1024 && !attr_set) {                                                                \
             hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
@@ -213,7 +219,7 @@ static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, u
             if (e0 != hipSuccess) return e0;                                                                     \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::N), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps,   \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * ROWS), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps, \
                            a.shift);                                                                             \
     } while (0)
     if (a.epilogue == EPI_LOGPSD) SDRK_ROW(EPI_LOGPSD); else SDRK_ROW(EPI_COMPLEX);
@@ -246,13 +252,15 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
             case 7: e = launch_col<7>(a, src, nf, M, cap(A)); break;
             case 8: e = launch_col<8>(a, src, nf, M, cap(A)); break;
             case 9: e = launch_col<9>(a, src, nf, M, cap(A)); break;
-            default: e = launch_col<10>(a, src, nf, M, cap(A)); break;
+            case 10: e = launch_col<10>(a, src, nf, M, cap(A)); break;
+            default: e = launch_col<11>(a, src, nf, M, cap(1024)); break;
         }
         if (e != hipSuccess) return e;
         switch (lm) {
             case 8: e = launch_row<8>(a, dst, nf, A, cap(M)); break;
             case 9: e = launch_row<9>(a, dst, nf, A, cap(M)); break;
-            default: e = launch_row<10>(a, dst, nf, A, cap(M)); break;
+            case 10: e = launch_row<10>(a, dst, nf, A, cap(M)); break;
+            default: e = launch_row<11>(a, dst, nf, A, cap(1024)); break;
         }
         if (e != hipSuccess) return e;
     }

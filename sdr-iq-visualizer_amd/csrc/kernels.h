@@ -30,7 +30,7 @@ struct LaunchArgs {
     void* d_scratch = nullptr;         // large-N plans: complex64 scratch, scratch_frames*nfft
     size_t scratch_frames = 0;
     const void* d_twiddle_big = nullptr;  // large-N plans: coarse/fine tables for W_nfft
-    const void* d_twiddle_2p = nullptr;   // two-pass tiled plans: W_A[1024] W_M[1024] t1T[(A/16)*M] t2[M*16]
+    const void* d_twiddle_2p = nullptr;   // two-pass tiled plans: W_A[2048] W_M[2048] t1T[(A/16)*M] t2[M*16]
 };
 
 // 20*log10(sqrt(re^2+im^2) + eps), the expression order of streamer.py:121:
@@ -57,7 +57,7 @@ hipError_t launch_fft_small(const LaunchArgs& a);   // 2 <= nfft <= 2048 (and 40
 hipError_t launch_fft_large(const LaunchArgs& a);   // nfft > 4096 (generic two-step)
 bool fft_lds_supports(int nfft);                     // 16 .. 16384 except 4096: registers + LDS, one pass over HBM
 hipError_t launch_fft_lds(const LaunchArgs& a);
-bool fft_tiled2_split(int nfft, int* log2a, int* log2m);   // 2^15 .. 2^20: N = A * M, both in LDS
+bool fft_tiled2_split(int nfft, int* log2a, int* log2m);   // 2^15 .. 2^22: N = A * M, both in LDS
 hipError_t launch_fft_tiled2(const LaunchArgs& a);
 bool fft_tiled_supports(int nfft);                   // 2^16 .. 2^20
 hipError_t launch_fft_tiled(const LaunchArgs& a);   // tiled 256 x R x 256 passes

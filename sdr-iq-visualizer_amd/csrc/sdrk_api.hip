@@ -485,14 +485,14 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
         const char* t3 = getenv("SDRK_TILED3");   // SDRK_TILED3=1: the older 256 x R x 256 three-pass form (A/B)
         if (sdrk::fft_tiled2_split(nfft, &la, &lm) && !(t3 && t3[0] == '1') && !p->force_generic) {
             const int A = 1 << la, M = 1 << lm, TA = A / 16;
-            std::vector<float2> t((size_t)2048 + (size_t)TA * M + (size_t)M * 16);
+            std::vector<float2> t((size_t)4096 + (size_t)TA * M + (size_t)M * 16);
             for (int m = 0; m < A; ++m) t[m] = twiddle(m, A);
-            for (int m = 0; m < M; ++m) t[1024 + m] = twiddle(m, M);
+            for (int m = 0; m < M; ++m) t[2048 + m] = twiddle(m, M);
             for (int tau = 0; tau < TA; ++tau)
-                for (int m = 0; m < M; ++m) t[2048 + (size_t)tau * M + m] = twiddle((double)m * tau, (double)nfft);
+                for (int m = 0; m < M; ++m) t[4096 + (size_t)tau * M + m] = twiddle((double)m * tau, (double)nfft);
             for (int m = 0; m < M; ++m)
                 for (int q = 0; q < 16; ++q)
-                    t[2048 + (size_t)TA * M + (size_t)m * 16 + q] = twiddle((double)m * TA * q, (double)nfft);
+                    t[4096 + (size_t)TA * M + (size_t)m * 16 + q] = twiddle((double)m * TA * q, (double)nfft);
             PLAN_TRY(hipMalloc((void**)&p->d_tw_2p, sizeof(float2) * t.size()));
             PLAN_TRY(hipMemcpy(p->d_tw_2p, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
             p->tiled2 = true;
