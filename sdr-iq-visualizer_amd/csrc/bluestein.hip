@@ -11,8 +11,7 @@
 //   blu_post  X[k] = conj(c[k]) * conj(Y[k]) / M ; fftshift (index + N/2 mod N, odd N included) ;
 //             20*log10(|X| + eps) or the complex value
 // The chirp table is built on the host in double precision with n^2 reduced mod 2N.
-#include "cplx.h"
-#include "kernels.h"
+#include "fft_lds_core.h"
 
 namespace sdrk {
 
@@ -64,6 +63,152 @@ __global__ __launch_bounds__(256) void blu_post_kernel(const float2* __restrict_
         else
             static_cast<float2*>(out_raw)[f * (size_t)N + dst] = make_float2(re, im);
     }
+}
+
+// ---- fused form for M <= 16384: the pre-multiply rides on the loads of the first transform, the filter
+// multiply (+ conjugation) on its stores, and the post-multiply / fftshift / log on the stores of the second:
+// two passes over the data instead of five.
+template <int LOG2M>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_fwd_kernel(
+    const float2* __restrict__ iq, size_t frame_stride, size_t n_frames, int N, const float* __restrict__ window,
+    const float2* __restrict__ chirp, const float2* __restrict__ bspec, const float2* __restrict__ twM,
+    float2* __restrict__ work) {
+    using C = LdsCfg<LOG2M>;
+    constexpr int M = C::N, P = C::P, R0 = C::R0, T = C::T, F = C::F, C0 = 16 / R0;
+    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
+    const int tid = threadIdx.x;
+    const int fr = tid / T, tau = tid - fr * T;
+    float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
+    LdsTw<LOG2M> tw;
+    lds_tw_init<LOG2M>(tw, twM, tau);
+    const size_t n_groups = (n_frames + F - 1) / F;
+    for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const size_t f = g * F + fr;
+        const bool ok = f < n_frames;
+        const float2* __restrict__ x = iq + (ok ? f : 0) * frame_stride;
+        cf v[16];
+#pragma unroll
+        for (int i = 0; i < C0; ++i)
+#pragma unroll
+            for (int j = 0; j < R0; ++j) {
+                const int n = tau + T * (i + C0 * j);
+                cf a = cf{0.f, 0.f};
+                if (ok && n < N) {
+                    float2 s = x[n];
+                    if (window) { const float w = window[n]; s.x *= w; s.y *= w; }
+                    const float2 c = chirp[n];  // times conj(c)
+                    a = cf{fmaf(s.x, c.x, s.y * c.y), fmaf(s.y, c.x, -(s.x * c.y))};
+                }
+                v[i * R0 + j] = a;
+            }
+        lds_fft_core<LOG2M, 1>(v, lds, 0, tau, tw);
+        if (ok) {
+            float2* __restrict__ o = work + f * (size_t)M;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = P == 1 ? q : tau + T * q;
+                const cf a = v[rev16(q)];
+                const float2 b = bspec[k];
+                o[k] = make_float2(fmaf(a.x, b.x, -(a.y * b.y)), -fmaf(a.x, b.y, a.y * b.x));  // conj(a*b)
+            }
+        }
+    }
+}
+
+template <int LOG2M, int EPILOGUE>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_inv_kernel(
+    const float2* __restrict__ work, size_t n_frames, int N, const float2* __restrict__ chirp,
+    const float2* __restrict__ twM, float eps, int shift, void* __restrict__ out_raw) {
+    using C = LdsCfg<LOG2M>;
+    constexpr int M = C::N, P = C::P, R0 = C::R0, T = C::T, F = C::F, C0 = 16 / R0;
+    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
+    const int tid = threadIdx.x;
+    const int fr = tid / T, tau = tid - fr * T;
+    float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
+    LdsTw<LOG2M> tw;
+    lds_tw_init<LOG2M>(tw, twM, tau);
+    const size_t n_groups = (n_frames + F - 1) / F;
+    const float inv_m = 1.0f / (float)M;
+    const int rot = shift ? N / 2 : 0;
+    for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const size_t f = g * F + fr;
+        const bool ok = f < n_frames;
+        const float2* __restrict__ x = work + (ok ? f : 0) * (size_t)M;
+        cf v[16];
+#pragma unroll
+        for (int i = 0; i < C0; ++i)
+#pragma unroll
+            for (int j = 0; j < R0; ++j) {
+                const float2 s = x[tau + T * (i + C0 * j)];
+                v[i * R0 + j] = ok ? cf{s.x, s.y} : cf{0.f, 0.f};
+            }
+        lds_fft_core<LOG2M, 1>(v, lds, 0, tau, tw);
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = P == 1 ? q : tau + T * q;
+                if (k < N) {
+                    const cf y = v[rev16(q)];
+                    const float2 c = chirp[k];
+                    const float re = fmaf(c.x, y.x, -(c.y * y.y)) * inv_m;   // conj(c) * conj(y) = conj(c y)
+                    const float im = -fmaf(c.x, y.y, c.y * y.x) * inv_m;
+                    int dst = k + rot;
+                    if (dst >= N) dst -= N;
+                    if (EPILOGUE == EPI_LOGPSD)
+                        static_cast<float*>(out_raw)[f * (size_t)N + dst] = logpsd_db(re, im, eps);
+                    else
+                        static_cast<float2*>(out_raw)[f * (size_t)N + dst] = make_float2(re, im);
+                }
+            }
+        }
+    }
+}
+
+template <int LOG2M>
+static hipError_t blu_fused_n(const void* d_iq, size_t frame_stride, size_t n_frames, int N, const float* d_window,
+                              const void* d_chirp, const void* d_bspec, const void* d_twM, void* d_work, float eps,
+                              int shift, int epilogue, void* d_out, int num_cus, hipStream_t s) {
+    using C = LdsCfg<LOG2M>;
+    const size_t lds_bytes = (size_t)C::F * C::SLOT * sizeof(float2);
+    size_t per_cu = (160 * 1024) / lds_bytes;
+    if (per_cu > (size_t)(2048 / C::WG)) per_cu = 2048 / C::WG;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const size_t n_groups = (n_frames + C::F - 1) / C::F, cap = (size_t)num_cus * per_cu;
+    const unsigned grid = (unsigned)(n_groups < cap ? n_groups : cap);
+    auto fwd = blu_fwd_kernel<LOG2M>;
+    auto inv0 = blu_inv_kernel<LOG2M, EPI_LOGPSD>;
+    auto inv1 = blu_inv_kernel<LOG2M, EPI_COMPLEX>;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(inv0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(inv1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fwd, dim3(grid), dim3(C::WG), lds_bytes, s, static_cast<const float2*>(d_iq), frame_stride, n_frames, N,
+                       d_window, static_cast<const float2*>(d_chirp), static_cast<const float2*>(d_bspec),
+                       static_cast<const float2*>(d_twM), static_cast<float2*>(d_work));
+    if (epilogue == EPI_LOGPSD)
+        hipLaunchKernelGGL(inv0, dim3(grid), dim3(C::WG), lds_bytes, s, static_cast<const float2*>(d_work), n_frames, N,
+                           static_cast<const float2*>(d_chirp), static_cast<const float2*>(d_twM), eps, shift, d_out);
+    else
+        hipLaunchKernelGGL(inv1, dim3(grid), dim3(C::WG), lds_bytes, s, static_cast<const float2*>(d_work), n_frames, N,
+                           static_cast<const float2*>(d_chirp), static_cast<const float2*>(d_twM), eps, shift, d_out);
+    return hipGetLastError();
+}
+
+bool blu_fused_supports(int M) { return M >= 16 && M <= 16384; }
+
+hipError_t launch_blu_fused(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
+                            const void* d_chirp, const void* d_bspec, const void* d_twM, void* d_work, float eps, int shift,
+                            int epilogue, void* d_out, int num_cus, hipStream_t s) {
+#define BLU_CASE(L) case (1 << L): return blu_fused_n<L>(d_iq, frame_stride, n_frames, N, d_window, d_chirp, d_bspec, d_twM, d_work, eps, shift, epilogue, d_out, num_cus, s);
+    switch (M) {
+        BLU_CASE(4) BLU_CASE(5) BLU_CASE(6) BLU_CASE(7) BLU_CASE(8) BLU_CASE(9) BLU_CASE(10) BLU_CASE(11) BLU_CASE(12)
+        BLU_CASE(13) BLU_CASE(14)
+        default: return hipErrorInvalidValue;
+    }
+#undef BLU_CASE
 }
 
 static unsigned blu_grid(size_t total, int num_cus) {

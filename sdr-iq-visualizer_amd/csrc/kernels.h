@@ -70,6 +70,10 @@ unsigned fused64k_max_slots(size_t n_frames, unsigned grid);
 size_t fused64k_ctrl_words_for(size_t n_frames, int num_cus);
 hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl, size_t ctrl_capacity_words);
 // arbitrary frame lengths (bluestein.hip)
+bool blu_fused_supports(int M);
+hipError_t launch_blu_fused(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
+                            const void* d_chirp, const void* d_bspec, const void* d_twM, void* d_work, float eps, int shift,
+                            int epilogue, void* d_out, int num_cus, hipStream_t s);
 hipError_t launch_blu_pre(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
                           const void* d_chirp, void* d_a, int num_cus, hipStream_t s);
 hipError_t launch_blu_mul(const void* d_A, const void* d_B, size_t n_frames, int M, void* d_out, int num_cus,

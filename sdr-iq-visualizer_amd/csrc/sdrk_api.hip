@@ -146,6 +146,14 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
         const size_t out_elem = epilogue == sdrk::EPI_LOGPSD ? sizeof(float) : sizeof(float2);
         for (size_t f0 = 0; f0 < n_frames; f0 += p->blu_frames) {
             const size_t nf = n_frames - f0 < p->blu_frames ? n_frames - f0 : p->blu_frames;
+            if (sdrk::blu_fused_supports(M) && !p->force_generic) {   // two passes instead of five
+                e = sdrk::launch_blu_fused(static_cast<const float2*>(d_iq) + f0 * frame_stride, frame_stride, nf, N, M,
+                                           p->d_window, p->d_blu_chirp, p->d_blu_bspec, p->blu_inner->d_twiddle,
+                                           p->d_blu_a, p->eps, p->shift, epilogue,
+                                           static_cast<char*>(d_out) + f0 * (size_t)N * out_elem, p->num_cus, stream);
+                if (e != hipSuccess) break;
+                continue;
+            }
             e = sdrk::launch_blu_pre(static_cast<const float2*>(d_iq) + f0 * frame_stride, frame_stride, nf, N, M,
                                      p->d_window, p->d_blu_chirp, p->d_blu_a, p->num_cus, stream);
             if (e != hipSuccess) break;
@@ -411,6 +419,8 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
     }
     if (!is_pow2(nfft)) {
         // Bluestein: inner power-of-two plan of size M >= 2N-1, chirp table, spectrum of the chirp filter
+        const char* genv0 = getenv("SDRK_GENERIC");   // =1: unfused five-pass form on the catch-all kernels (A/B)
+        p->force_generic = genv0 && genv0[0] == '1';
         int M = 1;
         while (M < 2 * nfft - 1) M <<= 1;
         p->blu_m = M;
