@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="budget for the numpy cpu_baseline leg (0 disables it)")
     ap.add_argument("--parity-frames", type=int, default=32)
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the oracle with one forked worker per visible host core (BASELINE.md §3; "
+                         "pure CPU, runs before any GPU runtime is loaded; do not use under rocprofv3)")
     return ap.parse_args()
 
 
@@ -84,6 +87,41 @@ def cpu_baseline(window: str, seconds: float):
     }
 
 
+def _cpu_worker(job):
+    """One forked worker of the all-cores leg: the batched oracle on its own frames for `seconds`."""
+    import numpy as np
+    from oracle import cpu_ref
+    from sdr_iq_visualizer_amd import synth
+    seed, window, seconds = job
+    frames = [synth.synth_iq(seed, c * 128, 128, NFFT) for c in range(4)]
+    w = np.hanning(NFFT).astype(np.float32) if window == "hann" else None
+    cpu_ref.spectrum_db(frames[0], window=w)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for f in frames:
+            cpu_ref.spectrum_db(f, window=w)
+        done += 128 * len(frames)
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(window: str, seconds: float):
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(1234 + i, window, seconds) for i in range(cores)])
+    total = sum(r[0] for r in res) * NFFT / max(r[1] for r in res) / 1e6
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 1)
+    except Exception:
+        pass
+    return {"value": round(total, 1), "unit": "Msamples/s", "workers": cores, "cgroup_cpu_quota": quota}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,6 +137,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(args.window, args.cpu_seconds)
+        if args.cpu_all_cores:
+            cpu["all_cores"] = cpu_baseline_all_cores(args.window, min(args.cpu_seconds, 5.0))
 
     import torch  # before libsdrk: one shared HIP runtime in the process (see _ffi.py)
     import numpy as np
