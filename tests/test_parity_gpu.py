@@ -591,3 +591,33 @@ def test_config3_full_size_sampled_rows(pkg):
     finally:
         lib.sdrk_dev_free(0, d_in)
         lib.sdrk_dev_free(0, d_out)
+
+
+def test_one_process_per_gpu_path_under_torchrun(pkg, tmp_path):
+    """sharding.distributed_spectrum_db with the product transform under torch.distributed (backend "nccl" =
+    RCCL) — one rank here, since this box has one GPU; the frame-range arithmetic for more ranks is covered
+    by the gloo tests.  Launched the way the driver launches bench.py."""
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "import numpy as np\n"
+        "from oracle import cpu_ref\n"
+        "from sdr_iq_visualizer_amd import sharding, synth\n"
+        "torch.cuda.set_device(int(os.environ['LOCAL_RANK']))\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', int(os.environ['LOCAL_RANK'])))\n"
+        "x = synth.synth_iq(9, 0, 37, 4096)\n"
+        "out = sharding.distributed_spectrum_db(x, window='hann')\n"
+        "ref = cpu_ref.spectrum_db(x, window=np.hanning(4096))\n"
+        "mg, mr = 10.0 ** (out.astype(np.float64) / 20), 10.0 ** (ref.astype(np.float64) / 20)\n"
+        "err = float((np.abs(mg - mr) / mr.max(axis=-1, keepdims=True)).max())\n"
+        "assert out.shape == (37, 4096) and err <= 1e-5, err\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rank ok', err)\n")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
