@@ -80,7 +80,20 @@ int main(int argc, char** argv) {
         a.tw_chain = true;
         time_it("fft4096 product-tree twiddles", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
     }
-    if (argc > 4) {   // placement experiment: same kernel, output (or input) buffer shifted / re-allocated
+    if (argc > 5) {   // single-slab experiment: input and output carved from ONE allocation at chosen offsets
+        void* slab; const size_t in_b = nf * 4096 * 8, out_b = nf * 4096 * 4;
+        CK(hipMalloc(&slab, in_b + out_b + ((size_t)1 << 30)));
+        CK(hipMemcpyAsync(slab, d_in, in_b, hipMemcpyDeviceToDevice, s)); CK(hipStreamSynchronize(s));
+        a.d_iq = slab;
+        for (size_t off : {(size_t)0, (size_t)256, (size_t)4096, (size_t)32768, (size_t)65536, (size_t)1 << 20, (size_t)2 << 20,
+                           (size_t)3 << 20, (size_t)16 << 20, (size_t)100 << 20, (size_t)512 << 20}) {
+            a.d_out = (char*)slab + in_b + off;
+            char name[64]; snprintf(name, sizeof name, "  slab: out at in_end +%zu KiB", off >> 10);
+            time_it(name, reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+        }
+        a.d_iq = d_in; a.d_out = d_out;
+        CK(hipFree(slab));
+    } else if (argc > 4) {   // placement experiment: same kernel, output (or input) buffer shifted / re-allocated
         for (size_t off : {(size_t)4096, (size_t)65536, (size_t)1 << 20, (size_t)3 << 20, (size_t)64 << 20}) {
             void* d_out2; CK(hipMalloc(&d_out2, nf * 4096 * 4 + off + (128 << 20)));
             a.d_out = (char*)d_out2 + off;
