@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
     CK(sdrk::launch_synth_fill(1234, 0, nf, 4096, d_in, s)); CK(hipStreamSynchronize(s));
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     double bytes = 12.0 * nf * 4096;
+    printf("d_in=%p d_out=%p\n", d_in, d_out);
     printf("variant: WAVES=%d TWCHAIN=%d FASTLOG=%d NT=%d ABLATE=%d  frames=2^%d window=%d\n", F4K_WAVES, F4K_TWCHAIN, -1, F4K_NT, F4K_ABLATE, lg, win);
     sdrk::LaunchArgs a; a.d_iq = d_in; a.frame_stride = 4096; a.d_out = d_out; a.n_frames = nf; a.nfft = 4096;
     a.d_window = win ? d_win : nullptr; a.d_twiddle = d_tw; a.stream = s; a.num_cus = prop.multiProcessorCount;
