@@ -35,6 +35,18 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     const int tiles = M / W;
     const size_t items = n_frames * (size_t)tiles;
 
+    // With the grid a multiple of the tiles per frame every workgroup keeps the same tile position for all
+    // its frames, so its 16 window coefficients per thread are loop invariants: keep them in registers
+    // (saves the 4 B/sample of L2 traffic the window costs; not at 1024 threads, where VGPRs are capped at 128).
+    constexpr bool WIN_REGS = HAS_WINDOW && (C::T * W <= 512);
+    const bool fixed_tile = WIN_REGS && (gridDim.x % tiles) == 0 && W == 16;
+    float wreg[16];
+    if (WIN_REGS && fixed_tile) {
+        const int m_fixed = (int)(blockIdx.x % tiles) * W + fr;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wreg[q] = window[(size_t)(tau + T * q) * M + m_fixed];
+    }
+
     for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
         // W == 8: the two tiles that share each 128-byte line go to blocks b and b+8 (same XCD under the
         // round-robin placement; a speed hint only)
@@ -55,7 +67,9 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
                 const int q = i + C0 * j;
                 v2f t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, 2));
                 if (HAS_WINDOW) {
-                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, e0 * 4, q * estep * 4, 0));
+                    float w;
+                    if (WIN_REGS && fixed_tile) w = wreg[q];
+                    else w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, e0 * 4, q * estep * 4, 0));
                     t.x *= w;
                     t.y *= w;
                 }
