@@ -39,7 +39,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     // its frames, so its 16 window coefficients per thread are loop invariants: keep them in registers
     // (saves the 4 B/sample of L2 traffic the window costs; not at 1024 threads, where VGPRs are capped at 128).
     constexpr bool WIN_REGS = HAS_WINDOW && (C::T * W <= 512);
-    const bool fixed_tile = WIN_REGS && (gridDim.x % tiles) == 0 && W == 16;
+    const bool fixed_tile = WIN_REGS && (gridDim.x % tiles) == 0 && W >= 16;
     float wreg[16];
     if (WIN_REGS && fixed_tile) {
         const int m_fixed = (int)(blockIdx.x % tiles) * W + fr;
@@ -96,7 +96,10 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
 #ifndef SDRK_COL_W1024
 #define SDRK_COL_W1024 16   // 8 (two 512-thread workgroups per CU, 64-byte segments) measured 10 % slower at N = 2^20
 #endif
-#define COL_TILE_W(LOG2A) ((LOG2A) == 11 ? 8 : ((LOG2A) == 10 ? SDRK_COL_W1024 : 16))
+#ifndef SDRK_COL_W256
+#define SDRK_COL_W256 16
+#endif
+#define COL_TILE_W(LOG2A) ((LOG2A) == 11 ? 8 : ((LOG2A) == 10 ? SDRK_COL_W1024 : ((LOG2A) == 8 ? SDRK_COL_W256 : 16)))
 #define ROW_TILE_R(LOG2M) ((LOG2M) == 11 ? 8 : 16)
 
 // ROWS = rows per tile (16, or 8 for M = 2048 so that the tile fits the LDS)
