@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SDRK_VERSION 100 /* 0.1.0 */
+#define SDRK_VERSION 200 /* 0.2.0 */
 
 typedef enum sdrk_status {
     SDRK_OK = 0,
@@ -92,6 +92,12 @@ int sdrk_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes);
 #define SDRK_MAX_LOG2_NFFT 22
 int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind,
                      const float* window, float eps, int shift, sdrk_plan** out);
+/* Same with option flags.  SDRK_PLAN_FUSED64K (nfft = 65536 only): run the transform as ONE persistent
+ * launch whose per-frame intermediate stays in each XCD's L2 (fft_fused64k.hip) instead of the two
+ * tiled launches — an experiment kept for A/B work (less HBM traffic, but slower: DESIGN.md §4.4). */
+#define SDRK_PLAN_FUSED64K 0x1u
+int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
+                        const float* window, float eps, int shift, unsigned flags, sdrk_plan** out);
 int sdrk_plan_destroy(sdrk_plan* plan);
 int sdrk_plan_nfft(const sdrk_plan* plan);
 int sdrk_plan_device(const sdrk_plan* plan);
@@ -100,7 +106,12 @@ int sdrk_plan_device(const sdrk_plan* plan);
  * frame f starts at sample f*frame_stride (frame_stride == nfft for packed
  * frames, == hop for an overlapped STFT over one contiguous stream; the buffer
  * must hold (n_frames-1)*frame_stride + nfft samples).  out_db: n_frames*nfft
- * float32, row-major.  Blocks until out_db is complete. */
+ * float32, row-major.  Blocks until out_db is complete.
+ * Calls of up to 256 KiB (the reference's live shape: one 4096-sample buffer,
+ * streamer.py:114-121) are served by a kernel that reads and writes pinned host
+ * memory directly; larger calls stream through pinned staging in ~16 MiB chunks,
+ * three in flight (staging memcpys by a small helper-thread pool, H2D, transform
+ * and D2H overlapped).  The caller's arrays may be ordinary pageable memory. */
 int sdrk_exec_host(sdrk_plan* plan, const void* iq_c64, size_t n_frames,
                    size_t frame_stride, float* out_db);
 
@@ -132,6 +143,26 @@ int sdrk_plan_sync(sdrk_plan* plan);
 int sdrk_exec_device_timed(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames,
                            size_t frame_stride, float* d_out_db, int launches,
                            float* elapsed_ms);
+
+/* The same, returning the elapsed milliseconds of each of the `launches` launches
+ * (events between consecutive launches; each_ms holds `launches` floats). */
+int sdrk_exec_device_timed_each(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames,
+                                size_t frame_stride, float* d_out_db, int launches, float* each_ms);
+
+/* ---- measurement probes (bench harness; no reference counterpart) ----------
+ * sdrk_stream_ceiling_probe: a plain streaming kernel with the spectrum path's traffic
+ *   shape at N = 4096 (32 KiB read + 16 KiB written per frame, no arithmetic), timed per
+ *   launch on device buffers the caller provides (d_in: n*32 KiB, d_out: n*16 KiB) — the
+ *   "measured-copy" ceiling SURVEY.md §8(d) asks to be reported next to the nominal 8 TB/s.
+ * sdrk_host_link_probe: pinned-memory DMA rates in GB/s — `bytes` host-to-device, bytes/2
+ *   device-to-host, and both at once (quoted on the upstream bytes): what the numpy
+ *   boundary could reach at best.
+ * sdrk_host_threads: helper threads of the host staging pool (SDRK_HOST_THREADS overrides). */
+int sdrk_stream_ceiling_probe(int device, const void* d_in, void* d_out, size_t n_frames4096,
+                              int launches, float* each_ms);
+int sdrk_host_link_probe(int device, size_t bytes, double* h2d_gbps, double* d2h_gbps,
+                         double* duplex_gbps);
+int sdrk_host_threads(void);
 
 /* ---- synthetic IQ generator (bench / parity input, device resident) ------
  * Sample n of frame F (F = first_frame + f, 64-bit) is

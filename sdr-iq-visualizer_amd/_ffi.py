@@ -16,7 +16,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p
 
 SDRK_OK = 0
 SDRK_ERR_INVALID = -1
@@ -30,6 +30,7 @@ WINDOW_HANN = 1
 WINDOW_CUSTOM = 2
 
 MAX_LOG2_NFFT = 22
+PLAN_FUSED64K = 0x1
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG_DIR, "lib", "libsdrk.so")
@@ -56,6 +57,8 @@ SYMBOLS = [
     ("sdrk_memcpy_d2h", c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     ("sdrk_plan_create", c_int,
      [c_int, c_int, c_size_t, c_int, c_void_p, c_float, c_int, POINTER(c_void_p)]),
+    ("sdrk_plan_create_ex", c_int,
+     [c_int, c_int, c_size_t, c_int, c_void_p, c_float, c_int, c_uint32, POINTER(c_void_p)]),
     ("sdrk_plan_destroy", c_int, [c_void_p]),
     ("sdrk_plan_nfft", c_int, [c_void_p]),
     ("sdrk_plan_device", c_int, [c_void_p]),
@@ -66,6 +69,11 @@ SYMBOLS = [
     ("sdrk_plan_sync", c_int, [c_void_p]),
     ("sdrk_exec_device_timed", c_int,
      [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float)]),
+    ("sdrk_exec_device_timed_each", c_int,
+     [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float)]),
+    ("sdrk_stream_ceiling_probe", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_float)]),
+    ("sdrk_host_link_probe", c_int, [c_int, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    ("sdrk_host_threads", c_int, []),
     ("sdrk_synth_fill", c_int, [c_int, c_uint32, c_uint64, c_size_t, c_int, c_void_p, c_void_p]),
     ("sdrk_row_stats", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p]),
     ("sdrk_row_peaks", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -110,6 +110,34 @@ hipError_t launch_decimate_rows(const float* d_ring, int nfft, int maxlen, int s
     return hipGetLastError();
 }
 
+// Streaming-copy ceiling with the spectrum path's traffic shape and nothing else: per 4096-sample
+// frame 32 KiB read (8 x 16 B per thread), 16 KiB written (4 x 16 B per thread), no arithmetic beyond one
+// add per output vector, non-temporal both ways, frames interleaved over a persistent grid of
+// 3 workgroups per CU (the flagship kernel's launch shape).  bench.py quotes the flagship's achieved GB/s
+// as a fraction of what THIS kernel reaches in the same process on the same buffers
+// ("report both nominal and measured-copy fractions").
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_mix_kernel(const v4f* __restrict__ in, v4f* __restrict__ out,
+                                                         size_t n_frames) {
+    for (size_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const v4f* x = in + f * 2048;
+        v4f* o = out + f * 1024;
+        v4f v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(&x[threadIdx.x + 256 * j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(v[2 * j] + v[2 * j + 1], &o[threadIdx.x + 256 * j]);
+    }
+}
+
+hipError_t launch_stream_mix(const void* d_in, void* d_out, size_t n_frames4096, int num_cus, hipStream_t stream) {
+    if (n_frames4096 == 0) return hipSuccess;
+    const size_t cap = (size_t)num_cus * 3;
+    hipLaunchKernelGGL(stream_mix_kernel, dim3((unsigned)(n_frames4096 < cap ? n_frames4096 : cap)), dim3(256), 0,
+                       stream, static_cast<const v4f*>(d_in), static_cast<v4f*>(d_out), n_frames4096);
+    return hipGetLastError();
+}
+
 hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,
                              hipStream_t stream) {
     hipLaunchKernelGGL(power_mean_kernel, dim3((nfft + 255) / 256), dim3(256), 0, stream,

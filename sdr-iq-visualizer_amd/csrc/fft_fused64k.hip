@@ -1,7 +1,7 @@
 // fft_fused64k.hip — N = 65536 (BASELINE.json config 3: the waterfall STFT) in ONE
 // persistent launch whose intermediate never leaves the XCD it was produced on.
 //
-// Same arithmetic as the two tiled passes of fft_tiled.hip (K1 col256: DFT-256 down
+// Same arithmetic as a two-pass 256 x 256 split (K1 col256: DFT-256 down
 // 16-wide column tiles, times W_N^(m k3); K3 row256: DFT-256 along 16 adjacent rows,
 // fftshift, log epilogue) — bit-identical results — but the 512 KiB complex64
 // intermediate of a frame lives in a small ring inside ONE XCD's 4 MiB L2 instead of
@@ -340,7 +340,7 @@ hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl, 
     if (e != hipSuccess) return e;
     const float2* iq = static_cast<const float2*>(a.d_iq);
     const float2* tw = static_cast<const float2*>(a.d_twiddle);
-    const float2* t1 = static_cast<const float2*>(a.d_twiddle_big) + 1024 + 4096;
+    const float2* t1 = static_cast<const float2*>(a.d_twiddle_fused);
     const float2* t2 = t1 + 256 * 16;
     float2* ring = static_cast<float2*>(d_ring);
 #define SDRK_FU(W, E)                                                                                  \

@@ -185,13 +185,9 @@ static hipError_t launch_lds_n(const LaunchArgs& a) {
     do {                                                                                                      \
         auto kern = (LOG2N <= 7 && staged) ? fft_lds_kernel<LOG2N, W, E, (LOG2N <= 7)>                        \
                                             : fft_lds_kernel<LOG2N, W, E, false>;                             \
-        static bool attr_set = false;   /* per instantiation; idempotent, so a benign race at worst */            \
-        if (lds_bytes > 64 * 1024 && !attr_set) {                                                             \
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-            if (e0 != hipSuccess) return e0;                                                                  \
-            attr_set = true;                                                                                  \
-        }                                                                                                     \
+        static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                  \
+        hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);           \
+        if (e0 != hipSuccess) return e0;                                                                      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::WG), lds_bytes, a.stream, iq, a.frame_stride, a.d_out,   \
                            a.n_frames, a.d_window, tw, a.eps, a.shift);                                       \
     } while (0)
@@ -204,7 +200,7 @@ static hipError_t launch_lds_n(const LaunchArgs& a) {
     return hipGetLastError();
 }
 
-bool fft_lds_supports(int nfft) { return nfft >= 16 && nfft <= 16384 && (nfft & (nfft - 1)) == 0; }
+bool fft_lds_supports(int nfft) { return nfft >= 16 && nfft <= 16384 && nfft != 4096 && (nfft & (nfft - 1)) == 0; }
 
 hipError_t launch_fft_lds(const LaunchArgs& a) {
     if (a.n_frames == 0) return hipSuccess;
@@ -221,7 +217,6 @@ hipError_t launch_fft_lds(const LaunchArgs& a) {
         case 512: return launch_lds_n<9>(a);
         case 1024: return launch_lds_n<10>(a);
         case 2048: return launch_lds_n<11>(a);
-        case 4096: return launch_lds_n<12>(a);
         case 8192: return launch_lds_n<13>(a);
         case 16384: return launch_lds_n<14>(a);
         default: return hipErrorInvalidValue;

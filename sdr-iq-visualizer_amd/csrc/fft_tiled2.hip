@@ -200,13 +200,9 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
 #define SDRK_COL(WIN)                                                                                            \
     do {                                                                                                         \
         auto kern = col_pass_kernel<LOG2A, WIN, W>;                                                              \
-        static bool attr_set = false;   /* per instantiation; idempotent, so a benign race at worst */               \
-        if (lds_bytes > 64 * 1024 && !attr_set) {                                                                \
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
-            if (e0 != hipSuccess) return e0;                                                                     \
-            attr_set = true;                                                                                     \
-        }                                                                                                        \
+        static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                     \
+        hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
+        if (e0 != hipSuccess) return e0;                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * W), lds_bytes, a.stream, src, a.frame_stride, scratch, nf, \
                            M, a.d_window, twA, t1T, t2);                                                            \
     } while (0)
@@ -229,13 +225,9 @@ static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, u
 #define SDRK_ROW(E)                                                                                              \
     do {                                                                                                         \
         auto kern = row_pass_kernel<LOG2M, E, ROWS>;                                                                   \
-        static bool attr_set = false;   /* per instantiation; idempotent, so a benign race at worst */               \
-        if (lds_bytes > 64 * 1024 && !attr_set) {                                                                \
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
-            if (e0 != hipSuccess) return e0;                                                                     \
-            attr_set = true;                                                                                     \
-        }                                                                                                        \
+        static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                     \
+        hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
+        if (e0 != hipSuccess) return e0;                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * ROWS), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps, \
                            a.shift);                                                                             \
     } while (0)

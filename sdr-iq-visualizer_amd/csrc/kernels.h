@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace sdrk {
 
 enum Epilogue : int {
@@ -29,7 +31,7 @@ struct LaunchArgs {
     int num_cus = 256;
     void* d_scratch = nullptr;         // large-N plans: complex64 scratch, scratch_frames*nfft
     size_t scratch_frames = 0;
-    const void* d_twiddle_big = nullptr;  // large-N plans: coarse/fine tables for W_nfft
+    const void* d_twiddle_fused = nullptr;  // fused N=65536 plans: W_N^(m k)[256][16] then W_N^(16 m q)[256][16]
     const void* d_twiddle_2p = nullptr;   // two-pass tiled plans: W_A[2048] W_M[2048] t1T[(A/16)*M] t2[M*16]
 };
 
@@ -52,15 +54,27 @@ __device__ __forceinline__ float logpsd_db_fast(float p) {
     return __builtin_amdgcn_logf(p) * 3.01029995663981195213f;  // log2 -> 10*log10
 }
 
+// Kernels that need more than 64 KiB of dynamic LDS must opt in with hipFuncSetAttribute, which acts on
+// the CURRENT device's function object: a process that drives several GPUs (sharding.py, channels.py)
+// has to do it once per device.  `mask` is the per-kernel-instantiation record (bit d = done on device d).
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t lds_bytes, std::atomic<uint64_t>& mask) {
+    if (lds_bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = (dev >= 0 && dev < 64) ? (uint64_t)1 << dev : 0;   // devices >= 64: set every time
+    if (bit && (mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess && bit) mask.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 hipError_t launch_fft4096(const LaunchArgs& a);
-hipError_t launch_fft_small(const LaunchArgs& a);   // 2 <= nfft <= 2048 (and 4096 for A/B)
-hipError_t launch_fft_large(const LaunchArgs& a);   // nfft > 4096 (generic two-step)
+hipError_t launch_fft_small(const LaunchArgs& a);   // 2 <= nfft <= 2048: Stockham radix-2 in LDS (N = 2, 4, 8 and far-apart frames)
 bool fft_lds_supports(int nfft);                     // 16 .. 16384 except 4096: registers + LDS, one pass over HBM
 hipError_t launch_fft_lds(const LaunchArgs& a);
 bool fft_tiled2_split(int nfft, int* log2a, int* log2m);   // 2^15 .. 2^22: N = A * M, both in LDS
 hipError_t launch_fft_tiled2(const LaunchArgs& a);
-bool fft_tiled_supports(int nfft);                   // 2^16 .. 2^20
-hipError_t launch_fft_tiled(const LaunchArgs& a);   // tiled 256 x R x 256 passes
 hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,
                              void* d_iq, hipStream_t stream);
 
@@ -85,6 +99,7 @@ hipError_t launch_row_peaks(const float* d_rows, size_t n_rows, int nfft, const 
                             int max_peaks, int* d_idx, int* d_count, hipStream_t s);
 hipError_t launch_decimate_rows(const float* d_ring, int nfft, int maxlen, int start_slot, int n_rows, int factor,
                                 int mode, float* d_out, hipStream_t stream);
+hipError_t launch_stream_mix(const void* d_in, void* d_out, size_t n_frames4096, int num_cus, hipStream_t stream);
 hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,
                              hipStream_t stream);
 

@@ -1,6 +1,7 @@
 // sdrk_api.hip — host side of the C ABI declared in include/sdrk.h: plans,
-// device staging, the waterfall ring, error reporting.  All compute is in the
-// gfx950 kernels (fft4096.hip, fft_small.hip, fft_large.hip, aux_kernels.hip);
+// device staging, the pinned host pipeline, the waterfall ring, error reporting.
+// All compute is in the gfx950 kernels (fft4096.hip, fft_lds.hip, fft_tiled2.hip,
+// fft_small.hip, bluestein.hip, fft_fused64k.hip, row_features.hip, aux_kernels.hip);
 // there is no host fallback anywhere in this file.
 #include "../../include/sdrk.h"
 
@@ -15,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "host_pool.h"
 #include "kernels.h"
 
 namespace {
@@ -64,6 +66,20 @@ float2 twiddle(double m, double n) {
 
 }  // namespace
 
+namespace {
+constexpr int HOST_SLOTS = 3;
+struct HostSlot {
+    void *h_in = nullptr, *h_out = nullptr;   // pinned
+    void *d_in = nullptr, *d_out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+    hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_done = nullptr;
+    // the chunk in flight in this slot (busy == true): where its rows go once ev_done has fired
+    bool busy = false;
+    void* user_out = nullptr;
+    size_t out_bytes = 0;
+};
+}  // namespace
+
 struct sdrk_plan {
     int device = 0;
     int nfft = 0;
@@ -75,17 +91,18 @@ struct sdrk_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float* d_window = nullptr;     // nfft floats, or nullptr for rectangular
     float2* d_twiddle = nullptr;   // W_min(nfft,4096)^m
-    float2* d_tw_big = nullptr;    // large plans: coarse[1024] then fine[4096]
+    float2* d_tw_fused = nullptr;  // fused N=65536 plans: the two [256][16] tables of fft_fused64k.hip
     float2* d_scratch = nullptr;   // large plans
     size_t scratch_frames = 0;
-    void* d_in = nullptr;          // staging for sdrk_exec_host (grown on demand)
+    void* d_in = nullptr;          // whole-stream staging (Welch PSD, waterfall append from host IQ); only grows
     size_t in_cap = 0;
     void* d_out = nullptr;
     size_t out_cap = 0;
     float2* d_tw_2p = nullptr;       // two-pass tiled plans (fft_tiled2.hip)
     bool tiled2 = false;
-    bool lds4096 = false;            // SDRK_LDS4096=1: run N=4096 through the generic in-LDS kernel (A/B vs fft4096.hip)
-    bool force_generic = false;      // SDRK_GENERIC=1: use the Stockham radix-2 catch-all kernels (A/B checks)
+    // sdrk_exec_host pipeline: HOST_SLOTS chunks in flight, each with pinned host and device staging
+    HostSlot slot[HOST_SLOTS];
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     // non-power-of-two lengths (bluestein.hip): inner power-of-two plan of size blu_m
     sdrk_plan* blu_inner = nullptr;
     int blu_m = 0;
@@ -107,7 +124,9 @@ struct sdrk_plan {
     unsigned fused_launches = 0;
 };
 constexpr size_t SMALL_IN_BYTES = 256 << 10;   // calls up to this much input take the zero-copy path
+constexpr size_t HOST_CHUNK_BYTES = 16 << 20;  // target input bytes per pipelined chunk of sdrk_exec_host
 constexpr unsigned FUSED_MAILBOX = 64;   // entries of 8 words: error flag + debug record
+constexpr size_t FUSED_PIECE = 1u << 16;  // frames per fused launch (sizes the control block once, at plan creation)
 
 struct sdrk_waterfall {
     int device = 0;
@@ -138,7 +157,7 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
     a.num_cus = p->num_cus;
     a.d_scratch = p->d_scratch;
     a.scratch_frames = p->scratch_frames;
-    a.d_twiddle_big = p->d_tw_big;
+    a.d_twiddle_fused = p->d_tw_fused;
     a.d_twiddle_2p = p->d_tw_2p;
     hipError_t e = hipSuccess;
     if (p->blu_inner) {
@@ -146,7 +165,7 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
         const size_t out_elem = epilogue == sdrk::EPI_LOGPSD ? sizeof(float) : sizeof(float2);
         for (size_t f0 = 0; f0 < n_frames; f0 += p->blu_frames) {
             const size_t nf = n_frames - f0 < p->blu_frames ? n_frames - f0 : p->blu_frames;
-            if (sdrk::blu_fused_supports(M) && !p->force_generic) {   // two passes instead of five
+            if (sdrk::blu_fused_supports(M)) {   // two passes instead of five
                 e = sdrk::launch_blu_fused(static_cast<const float2*>(d_iq) + f0 * frame_stride, frame_stride, nf, N, M,
                                            p->d_window, p->d_blu_chirp, p->d_blu_bspec, p->blu_inner->d_twiddle,
                                            p->d_blu_a, p->eps, p->shift, epilogue,
@@ -167,28 +186,20 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
                                       static_cast<char*>(d_out) + f0 * (size_t)N * out_elem, p->num_cus, stream);
             if (e != hipSuccess) break;
         }
-    } else if (p->nfft == 4096 && !p->lds4096)
+    } else if (p->nfft == 4096)
         e = sdrk::launch_fft4096(a);
-    else if (sdrk::fft_lds_supports(p->nfft) && !p->force_generic)
+    else if (sdrk::fft_lds_supports(p->nfft))
         e = sdrk::launch_fft_lds(a);
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
     else if (p->fused64k) {
-        // largest launch the control block was sized for; longer batches go through in pieces
-        const size_t piece = 1u << 20;
+        // the control block was sized at plan creation for FUSED_PIECE frames; longer batches go through in pieces
         e = hipSuccess;
-        for (size_t f0 = 0; f0 < n_frames && e == hipSuccess; f0 += piece) {
+        for (size_t f0 = 0; f0 < n_frames && e == hipSuccess; f0 += FUSED_PIECE) {
             sdrk::LaunchArgs b = a;
-            b.n_frames = n_frames - f0 < piece ? n_frames - f0 : piece;
+            b.n_frames = n_frames - f0 < FUSED_PIECE ? n_frames - f0 : FUSED_PIECE;
             b.d_iq = static_cast<const float2*>(d_iq) + f0 * frame_stride;
             b.d_out = static_cast<char*>(d_out) + f0 * (size_t)p->nfft * (epilogue == sdrk::EPI_LOGPSD ? 4 : 8);
-            const size_t need = sdrk::fused64k_ctrl_words_for(b.n_frames, p->num_cus);
-            if (need > p->fused_ctrl_words) {
-                if (p->d_fused_ctrl) { (void)hipStreamSynchronize(stream); (void)hipFree(p->d_fused_ctrl); p->d_fused_ctrl = nullptr; p->fused_ctrl_words = 0; }
-                e = hipMalloc((void**)&p->d_fused_ctrl, need * sizeof(unsigned));
-                if (e != hipSuccess) break;
-                p->fused_ctrl_words = need;
-            }
             e = sdrk::launch_fused64k(b, p->d_fused_ring, p->d_fused_ctrl, p->fused_ctrl_words);
             if (e == hipSuccess)
                 e = hipMemcpyAsync(p->h_fused_err + 16 * (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl + 1,
@@ -196,10 +207,8 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
         }
     } else if (p->tiled2)
         e = sdrk::launch_fft_tiled2(a);
-    else if (sdrk::fft_tiled_supports(p->nfft))
-        e = sdrk::launch_fft_tiled(a);
     else
-        e = sdrk::launch_fft_large(a);
+        return fail(SDRK_ERR_UNSUPPORTED, "no kernel for nfft=%d", p->nfft);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return SDRK_OK;
 }
@@ -236,6 +245,7 @@ int check_exec_args(const sdrk_plan* p, const void* in, size_t n_frames, size_t 
     return SDRK_OK;
 }
 
+// Device staging that only ever grows (no free + malloc per call once the largest size has been seen).
 int grow(int device, void** buf, size_t* cap, size_t need) {
     if (need <= *cap) return SDRK_OK;
     if (*buf) {
@@ -243,12 +253,68 @@ int grow(int device, void** buf, size_t* cap, size_t need) {
         *buf = nullptr;
         *cap = 0;
     }
-    HIP_TRY(hipMalloc(buf, need));
-    *cap = need;
+    const size_t want = need + need / 4;   // head-room: a slightly larger next call does not reallocate
+    if (hipMalloc(buf, want) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipMalloc(buf, need));
+        *cap = need;
+    } else {
+        *cap = want;
+    }
     (void)device;
     return SDRK_OK;
 }
 
+int slot_reserve(sdrk_plan* p, HostSlot& s, size_t in_bytes, size_t out_bytes) {
+    if (!s.ev_in) {
+        HIP_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    }
+    if (in_bytes > s.in_cap) {
+        if (s.h_in) HIP_TRY(hipHostFree(s.h_in));
+        if (s.d_in) HIP_TRY(hipFree(s.d_in));
+        s.h_in = s.d_in = nullptr;
+        s.in_cap = 0;
+        HIP_TRY(hipHostMalloc(&s.h_in, in_bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&s.d_in, in_bytes));
+        s.in_cap = in_bytes;
+    }
+    if (out_bytes > s.out_cap) {
+        if (s.h_out) HIP_TRY(hipHostFree(s.h_out));
+        if (s.d_out) HIP_TRY(hipFree(s.d_out));
+        s.h_out = s.d_out = nullptr;
+        s.out_cap = 0;
+        HIP_TRY(hipHostMalloc(&s.h_out, out_bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&s.d_out, out_bytes));
+        s.out_cap = out_bytes;
+    }
+    (void)p;
+    return SDRK_OK;
+}
+
+// Wait for the chunk in flight in slot `s` and hand its rows to the caller's array.
+int slot_retire(HostSlot& s) {
+    if (!s.busy) return SDRK_OK;
+    s.busy = false;
+    HIP_TRY(hipEventSynchronize(s.ev_done));
+    sdrk::CopyPool::get().copy(s.user_out, s.h_out, s.out_bytes);
+    return SDRK_OK;
+}
+
+void slots_abandon(sdrk_plan* p) {   // error path: nothing may still be writing into the staging buffers
+    (void)hipStreamSynchronize(p->s_h2d);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipStreamSynchronize(p->s_d2h);
+    for (auto& s : p->slot) s.busy = false;
+}
+
+// The numpy boundary.  Small calls (the live app's one 4096-sample buffer, streamer.py:114-121): the
+// kernel reads and writes pinned mapped host memory, no DMA copies.  Everything else: the frames go
+// through in chunks of ~16 MiB, HOST_SLOTS of them in flight — helper threads copy the caller's pageable
+// memory into a pinned slot, then H2D (copy stream) -> transform (plan stream) -> D2H (copy stream) run
+// asynchronously, chained by events, while the host stages the next chunk and drains finished ones.
+// H2D of chunk c+1 overlaps D2H of chunk c (PCIe is full duplex) and both overlap the staging memcpys.
 int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride, void* out,
                      int epilogue) {
     int st = check_exec_args(p, iq, n_frames, frame_stride, out);
@@ -257,13 +323,12 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
         return fail(SDRK_ERR_INVALID, "n_frames %zu exceeds the plan's max_batch %zu", n_frames,
                     p->max_batch);
     HIP_TRY(hipSetDevice(p->device));
-    const size_t in_samples = (n_frames - 1) * frame_stride + (size_t)p->nfft;
+    const size_t nfft = (size_t)p->nfft;
+    const size_t in_samples = (n_frames - 1) * frame_stride + nfft;
     const size_t in_bytes = in_samples * sizeof(float2);
     const size_t out_elem = epilogue == sdrk::EPI_LOGPSD ? sizeof(float) : sizeof(float2);
-    const size_t out_bytes = n_frames * (size_t)p->nfft * out_elem;
+    const size_t out_bytes = n_frames * nfft * out_elem;
     if (in_bytes <= SMALL_IN_BYTES && out_bytes <= SMALL_IN_BYTES && p->nfft <= 4096 && !p->blu_inner) {
-        // The live app's call shape (one 4096-sample buffer per call, streamer.py:114-121): latency matters,
-        // not bandwidth.  The kernel reads the frame from, and writes the row to, pinned host memory.
         if (!p->h_small_in) {
             HIP_TRY(hipHostMalloc(&p->h_small_in, SMALL_IN_BYTES, hipHostMallocMapped));
             HIP_TRY(hipHostMalloc(&p->h_small_out, SMALL_IN_BYTES, hipHostMallocMapped));
@@ -278,15 +343,55 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
         memcpy(out, p->h_small_out, out_bytes);
         return SDRK_OK;
     }
-    st = grow(p->device, &p->d_in, &p->in_cap, in_bytes);
-    if (st != SDRK_OK) return st;
-    st = grow(p->device, &p->d_out, &p->out_cap, out_bytes);
-    if (st != SDRK_OK) return st;
-    HIP_TRY(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
-    st = plan_launch(p, p->d_in, n_frames, frame_stride, p->d_out, epilogue, p->stream);
-    if (st != SDRK_OK) return st;
-    HIP_TRY(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (!p->s_h2d) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking));
+    }
+    // frames per chunk: ~HOST_CHUNK_BYTES of input, but at least 4 chunks per call when the call is big
+    // enough for the overlap to matter, and never less than one frame
+    const size_t stride_bytes = (frame_stride ? frame_stride : 1) * sizeof(float2);
+    size_t target = HOST_CHUNK_BYTES;
+    if (in_bytes / 4 < target) target = in_bytes / 4 > ((size_t)1 << 20) ? in_bytes / 4 : ((size_t)1 << 20);
+    size_t per = target / stride_bytes;
+    if (per > target / (nfft * out_elem)) per = target / (nfft * out_elem);   // heavily overlapped frames: bound the rows too
+    if (per < 1) per = 1;
+    if (per > n_frames) per = n_frames;
+    const size_t chunk_in = ((per - 1) * frame_stride + nfft) * sizeof(float2);
+    const size_t chunk_out = per * nfft * out_elem;
+    sdrk::CopyPool& pool = sdrk::CopyPool::get();
+    size_t c = 0;
+    for (size_t f0 = 0; f0 < n_frames; f0 += per, ++c) {
+        HostSlot& s = p->slot[c % HOST_SLOTS];
+        const size_t nf = n_frames - f0 < per ? n_frames - f0 : per;
+        const size_t cin = ((nf - 1) * frame_stride + nfft) * sizeof(float2);
+        const size_t cout = nf * nfft * out_elem;
+        st = slot_retire(s);                                   // chunk c - HOST_SLOTS: rows out, slot free
+        if (st == SDRK_OK) st = slot_reserve(p, s, chunk_in, chunk_out);
+        if (st != SDRK_OK) { slots_abandon(p); return st; }
+        pool.copy(s.h_in, static_cast<const float2*>(iq) + f0 * frame_stride, cin);
+        hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, cin, hipMemcpyHostToDevice, p->s_h2d);
+        if (e == hipSuccess) e = hipEventRecord(s.ev_in, p->s_h2d);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, s.ev_in, 0);
+        if (e == hipSuccess) {
+            st = plan_launch(p, s.d_in, nf, frame_stride, s.d_out, epilogue, p->stream);
+            if (st != SDRK_OK) { slots_abandon(p); return st; }
+            e = hipEventRecord(s.ev_k, p->stream);
+        }
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->s_d2h, s.ev_k, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.h_out, s.d_out, cout, hipMemcpyDeviceToHost, p->s_d2h);
+        if (e == hipSuccess) e = hipEventRecord(s.ev_done, p->s_d2h);
+        if (e != hipSuccess) {
+            slots_abandon(p);
+            return fail(SDRK_ERR_HIP, "host pipeline failed: %s", hipGetErrorString(e));
+        }
+        s.busy = true;
+        s.user_out = static_cast<char*>(out) + f0 * nfft * out_elem;
+        s.out_bytes = cout;
+    }
+    for (size_t i = 0; i < HOST_SLOTS; ++i) {                  // drain in submission order
+        st = slot_retire(p->slot[(c + i) % HOST_SLOTS]);
+        if (st != SDRK_OK) { slots_abandon(p); return st; }
+    }
     return fused_check(p);
 }
 
@@ -360,8 +465,16 @@ int sdrk_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes) {
 
 int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, const float* window,
                      float eps, int shift, sdrk_plan** out) {
+    return sdrk_plan_create_ex(device, nfft, max_batch, window_kind, window, eps, shift, 0u, out);
+}
+
+int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind, const float* window,
+                        float eps, int shift, unsigned flags, sdrk_plan** out) {
     if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
     *out = nullptr;
+    if (flags & ~(unsigned)SDRK_PLAN_FUSED64K) return fail(SDRK_ERR_INVALID, "unknown plan flags 0x%x", flags);
+    if ((flags & SDRK_PLAN_FUSED64K) && nfft != 65536)
+        return fail(SDRK_ERR_INVALID, "SDRK_PLAN_FUSED64K applies to nfft = 65536 only (got %d)", nfft);
     if (nfft < 2 || nfft > (1 << SDRK_MAX_LOG2_NFFT) || (!is_pow2(nfft) && nfft > (1 << (SDRK_MAX_LOG2_NFFT - 1))))
         return fail(SDRK_ERR_INVALID, "nfft=%d: must be in [2, 2^%d] (powers of two) or [2, 2^%d] (any other length)",
                     nfft, SDRK_MAX_LOG2_NFFT, SDRK_MAX_LOG2_NFFT - 1);
@@ -419,8 +532,6 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
     }
     if (!is_pow2(nfft)) {
         // Bluestein: inner power-of-two plan of size M >= 2N-1, chirp table, spectrum of the chirp filter
-        const char* genv0 = getenv("SDRK_GENERIC");   // =1: unfused five-pass form on the catch-all kernels (A/B)
-        p->force_generic = genv0 && genv0[0] == '1';
         int M = 1;
         while (M < 2 * nfft - 1) M <<= 1;
         p->blu_m = M;
@@ -451,34 +562,15 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
         *out = p;
         return SDRK_OK;
     }
-    // twiddles of the in-LDS transform
-    {
-        const char* genv = getenv("SDRK_GENERIC");
-        p->force_generic = genv && genv[0] == '1';
-        const char* l4 = getenv("SDRK_LDS4096");
-        p->lds4096 = l4 && l4[0] == '1';
-        // W_N for the in-LDS kernels (N <= 16384); the 4096 table for everything built on fft4096_core.h
-        const int tn = (nfft <= 16384 && !(p->force_generic && nfft > 4096)) ? nfft : 4096;
-        std::vector<float2> t(tn);
-        for (int m = 0; m < tn; ++m) t[m] = twiddle(m, tn);
-        PLAN_TRY(hipMalloc((void**)&p->d_twiddle, sizeof(float2) * tn));
-        PLAN_TRY(hipMemcpy(p->d_twiddle, t.data(), sizeof(float2) * tn, hipMemcpyHostToDevice));
-    }
-    if (nfft > 4096) {
-        const int n1 = nfft / 4096;
-        const bool tiled = sdrk::fft_tiled_supports(nfft);
-        const int M = tiled ? nfft / 256 : 0;   // tiled plans: [m][p] = W_N^(m p), [m][q] = W_N^(16 m q)
-        std::vector<float2> t(1024 + 4096 + (size_t)2 * M * 16);
-        for (int m = 0; m < 1024; ++m) t[m] = twiddle(m % n1, n1);           // coarse: W_N1^m = W_N^(4096 m)
-        for (int m = 0; m < 4096; ++m) t[1024 + m] = twiddle(m, (double)nfft);  // fine: W_N^m
-        for (int m = 0; m < M; ++m)
-            for (int k = 0; k < 16; ++k) {
-                t[1024 + 4096 + (size_t)m * 16 + k] = twiddle((double)m * k, (double)nfft);
-                t[1024 + 4096 + (size_t)M * 16 + (size_t)m * 16 + k] = twiddle(16.0 * m * k, (double)nfft);
-            }
-        PLAN_TRY(hipMalloc((void**)&p->d_tw_big, sizeof(float2) * t.size()));
-        PLAN_TRY(hipMemcpy(p->d_tw_big, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
-        // scratch: up to 128 MiB of complex64 frames (stays in the 256 MiB Infinity Cache)
+    // twiddles of the in-LDS transform: W_N for N <= 16384 (fft4096.hip, fft_lds.hip, fft_small.hip); the
+    // two-pass plans carry their own tables below
+    if (nfft <= 16384) {
+        std::vector<float2> t(nfft);
+        for (int m = 0; m < nfft; ++m) t[m] = twiddle(m, nfft);
+        PLAN_TRY(hipMalloc((void**)&p->d_twiddle, sizeof(float2) * nfft));
+        PLAN_TRY(hipMemcpy(p->d_twiddle, t.data(), sizeof(float2) * nfft, hipMemcpyHostToDevice));
+    } else {
+        // scratch between the two passes: up to 128 MiB of complex64 frames (stays in the 256 MiB Infinity Cache)
         size_t scratch_mb = 128;
         if (const char* env = getenv("SDRK_SCRATCH_MB")) {  // tuning knob (developer use)
             long v = atol(env);
@@ -489,36 +581,45 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, co
         if (frames > max_batch) frames = max_batch;
         p->scratch_frames = frames;
         PLAN_TRY(hipMalloc((void**)&p->d_scratch, frames * (size_t)nfft * sizeof(float2)));
-    }
-    {
         int la = 0, lm = 0;
-        const char* t3 = getenv("SDRK_TILED3");   // SDRK_TILED3=1: the older 256 x R x 256 three-pass form (A/B)
-        if (sdrk::fft_tiled2_split(nfft, &la, &lm) && !(t3 && t3[0] == '1') && !p->force_generic) {
-            const int A = 1 << la, M = 1 << lm, TA = A / 16;
-            std::vector<float2> t((size_t)4096 + (size_t)TA * M + (size_t)M * 16);
-            for (int m = 0; m < A; ++m) t[m] = twiddle(m, A);
-            for (int m = 0; m < M; ++m) t[2048 + m] = twiddle(m, M);
-            for (int tau = 0; tau < TA; ++tau)
-                for (int m = 0; m < M; ++m) t[4096 + (size_t)tau * M + m] = twiddle((double)m * tau, (double)nfft);
-            for (int m = 0; m < M; ++m)
-                for (int q = 0; q < 16; ++q)
-                    t[4096 + (size_t)TA * M + (size_t)m * 16 + q] = twiddle((double)m * TA * q, (double)nfft);
-            PLAN_TRY(hipMalloc((void**)&p->d_tw_2p, sizeof(float2) * t.size()));
-            PLAN_TRY(hipMemcpy(p->d_tw_2p, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
-            p->tiled2 = true;
+        if (!sdrk::fft_tiled2_split(nfft, &la, &lm)) {
+            sdrk_plan_destroy(p);
+            return fail(SDRK_ERR_UNSUPPORTED, "no kernel for nfft=%d", nfft);
         }
+        const int A = 1 << la, M = 1 << lm, TA = A / 16;
+        std::vector<float2> t((size_t)4096 + (size_t)TA * M + (size_t)M * 16);
+        for (int m = 0; m < A; ++m) t[m] = twiddle(m, A);
+        for (int m = 0; m < M; ++m) t[2048 + m] = twiddle(m, M);
+        for (int tau = 0; tau < TA; ++tau)
+            for (int m = 0; m < M; ++m) t[4096 + (size_t)tau * M + m] = twiddle((double)m * tau, (double)nfft);
+        for (int m = 0; m < M; ++m)
+            for (int q = 0; q < 16; ++q)
+                t[4096 + (size_t)TA * M + (size_t)m * 16 + q] = twiddle((double)m * TA * q, (double)nfft);
+        PLAN_TRY(hipMalloc((void**)&p->d_tw_2p, sizeof(float2) * t.size()));
+        PLAN_TRY(hipMemcpy(p->d_tw_2p, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
+        p->tiled2 = true;
     }
-    if (nfft == 65536) {
-        // Experimental single-launch, XCD-resident form (fft_fused64k.hip): opt in with SDRK_FUSED64K=1.
-        // Round-1 measurements: HBM traffic 14-21 B/sample instead of 28, but 1.4x slower than the two tiled
-        // launches (dependency stalls between the K1 and K3 tiles of a frame), so the tiled path stays default.
-        const char* env = getenv("SDRK_FUSED64K");
-        p->fused64k = env && env[0] == '1';
-        if (p->fused64k) {
-            PLAN_TRY(hipMalloc(&p->d_fused_ring, sdrk::fused64k_ring_bytes()));
-            PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * 16 * sizeof(unsigned), hipHostMallocDefault));
-            memset(p->h_fused_err, 0, FUSED_MAILBOX * 16 * sizeof(unsigned));
-        }
+    if (flags & SDRK_PLAN_FUSED64K) {
+        // Experimental single-launch, XCD-resident form of N = 65536 (fft_fused64k.hip).  Round-1 measurements:
+        // HBM traffic 14-21 B/sample instead of 28, but 1.4x slower than the two tiled launches (dependency
+        // stalls between the K1 and K3 tiles of a frame), so it is an explicit opt-in.
+        p->fused64k = true;
+        std::vector<float2> t((size_t)2 * 256 * 16), w4096(4096);
+        for (int m = 0; m < 256; ++m)
+            for (int k = 0; k < 16; ++k) {
+                t[(size_t)m * 16 + k] = twiddle((double)m * k, 65536.0);
+                t[(size_t)256 * 16 + (size_t)m * 16 + k] = twiddle(16.0 * m * k, 65536.0);
+            }
+        for (int m = 0; m < 4096; ++m) w4096[m] = twiddle(m, 4096);
+        PLAN_TRY(hipMalloc((void**)&p->d_tw_fused, sizeof(float2) * t.size()));
+        PLAN_TRY(hipMemcpy(p->d_tw_fused, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
+        PLAN_TRY(hipMalloc((void**)&p->d_twiddle, sizeof(float2) * 4096));   // the kernel's in-LDS sub-transforms use W_4096
+        PLAN_TRY(hipMemcpy(p->d_twiddle, w4096.data(), sizeof(float2) * 4096, hipMemcpyHostToDevice));
+        PLAN_TRY(hipMalloc(&p->d_fused_ring, sdrk::fused64k_ring_bytes()));
+        p->fused_ctrl_words = sdrk::fused64k_ctrl_words_for(FUSED_PIECE, p->num_cus);
+        PLAN_TRY(hipMalloc((void**)&p->d_fused_ctrl, p->fused_ctrl_words * sizeof(unsigned)));
+        PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * 16 * sizeof(unsigned), hipHostMallocDefault));
+        memset(p->h_fused_err, 0, FUSED_MAILBOX * 16 * sizeof(unsigned));
     }
 #undef PLAN_TRY
     *out = p;
@@ -531,7 +632,7 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->d_window) (void)hipFree(p->d_window);
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
-    if (p->d_tw_big) (void)hipFree(p->d_tw_big);
+    if (p->d_tw_fused) (void)hipFree(p->d_tw_fused);
     if (p->d_tw_2p) (void)hipFree(p->d_tw_2p);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->blu_inner) (void)sdrk_plan_destroy(p->blu_inner);
@@ -546,6 +647,19 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->h_fused_err) (void)hipHostFree(p->h_fused_err);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
+    if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
+    if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
+    for (auto& sl : p->slot) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_k) (void)hipEventDestroy(sl.ev_k);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
+    if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -595,6 +709,8 @@ int sdrk_welch_psd_host(sdrk_plan* p, const void* iq, size_t n_frames, size_t fr
         if (e != hipSuccess) return fail(SDRK_ERR_HIP, "power_mean launch failed: %s", hipGetErrorString(e));
         HIP_TRY(hipMemcpyAsync(row.data(), d_row, nfft * sizeof(float), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
+        st = fused_check(p);
+        if (st != SDRK_OK) return st;
         for (size_t k = 0; k < nfft; ++k) total[k] += row[k];   // <= a handful of chunks
     }
     memcpy(out_psd, total.data(), nfft * sizeof(float));
@@ -633,6 +749,112 @@ int sdrk_exec_device_timed(sdrk_plan* p, const void* d_iq, size_t n_frames, size
     HIP_TRY(hipEventElapsedTime(elapsed_ms, p->ev0, p->ev1));
     return fused_check(p);
 }
+
+int sdrk_exec_device_timed_each(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride,
+                                float* d_out_db, int launches, float* each_ms) {
+    if (!each_ms || launches < 1 || launches > 4096) return fail(SDRK_ERR_INVALID, "bad launches/each_ms");
+    int st = check_exec_args(p, d_iq, n_frames, frame_stride, d_out_db);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<hipEvent_t> ev((size_t)launches + 1, nullptr);
+    auto cleanup = [&] { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) { cleanup(); return fail(SDRK_ERR_HIP, "hipEventCreate failed"); }
+    hipError_t e = hipEventRecord(ev[0], p->stream);
+    for (int i = 0; i < launches && e == hipSuccess; ++i) {
+        st = plan_launch(p, d_iq, n_frames, frame_stride, d_out_db, sdrk::EPI_LOGPSD, p->stream);
+        if (st != SDRK_OK) { (void)hipStreamSynchronize(p->stream); cleanup(); return st; }
+        e = hipEventRecord(ev[(size_t)i + 1], p->stream);
+    }
+    if (e == hipSuccess) e = hipEventSynchronize(ev[(size_t)launches]);
+    for (int i = 0; i < launches && e == hipSuccess; ++i) e = hipEventElapsedTime(&each_ms[i], ev[i], ev[(size_t)i + 1]);
+    cleanup();
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "timed launches failed: %s", hipGetErrorString(e));
+    return fused_check(p);
+}
+
+int sdrk_stream_ceiling_probe(int device, const void* d_in, void* d_out, size_t n_frames4096, int launches,
+                              float* each_ms) {
+    if (!d_in || !d_out || !each_ms || launches < 1 || launches > 4096 || n_frames4096 == 0)
+        return fail(SDRK_ERR_INVALID, "bad argument");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    for (int i = -2; i < launches && e == hipSuccess; ++i) {     // two untimed warm-ups
+        if (i >= 0) e = hipEventRecord(e0, s);
+        if (e == hipSuccess) e = sdrk::launch_stream_mix(d_in, d_out, n_frames4096, prop.multiProcessorCount, s);
+        if (i >= 0 && e == hipSuccess) e = hipEventRecord(e1, s);
+        if (i >= 0 && e == hipSuccess) e = hipEventSynchronize(e1);
+        if (i >= 0 && e == hipSuccess) e = hipEventElapsedTime(&each_ms[i], e0, e1);
+    }
+    (void)hipStreamSynchronize(s);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "stream ceiling probe failed: %s", hipGetErrorString(e));
+    return SDRK_OK;
+}
+
+int sdrk_host_link_probe(int device, size_t bytes, double* h2d_gbps, double* d2h_gbps, double* duplex_gbps) {
+    if (!h2d_gbps || !d2h_gbps || !duplex_gbps || bytes < (1u << 20)) return fail(SDRK_ERR_INVALID, "bad argument");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    void *h_a = nullptr, *h_b = nullptr, *d_a = nullptr, *d_b = nullptr;
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    hipError_t e = hipHostMalloc(&h_a, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&h_b, bytes / 2, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&d_a, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_b, bytes / 2);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s0, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventCreate(&e2);
+    if (e == hipSuccess) memset(h_a, 1, bytes);
+    float ms = 0.f;
+    auto timed = [&](bool up, bool down, double* gbps, double moved) {
+        for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {       // keep the last of three
+            e = hipEventRecord(e0, s0);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s1, e0, 0);
+            if (up && e == hipSuccess) e = hipMemcpyAsync(d_a, h_a, bytes, hipMemcpyHostToDevice, s0);
+            if (down && e == hipSuccess) e = hipMemcpyAsync(h_b, d_b, bytes / 2, hipMemcpyDeviceToHost, s1);
+            if (e == hipSuccess) e = hipEventRecord(e2, s1);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s0, e2, 0);
+            if (e == hipSuccess) e = hipEventRecord(e1, s0);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        }
+        if (e == hipSuccess) *gbps = moved / (ms * 1e-3) / 1e9;
+    };
+    timed(true, false, h2d_gbps, (double)bytes);
+    timed(false, true, d2h_gbps, (double)(bytes / 2));
+    // the spectrum path's mix: `bytes` up while bytes/2 come down; rate quoted on the upstream bytes
+    timed(true, true, duplex_gbps, (double)bytes);
+    if (s0) (void)hipStreamSynchronize(s0);
+    if (s1) (void)hipStreamSynchronize(s1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
+    if (s0) (void)hipStreamDestroy(s0);
+    if (s1) (void)hipStreamDestroy(s1);
+    if (h_a) (void)hipHostFree(h_a);
+    if (h_b) (void)hipHostFree(h_b);
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "host link probe failed: %s", hipGetErrorString(e));
+    return SDRK_OK;
+}
+
+int sdrk_host_threads(void) { return sdrk::CopyPool::get().helpers(); }
 
 int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,
                     void* d_iq, void* stream) {
@@ -809,7 +1031,7 @@ int sdrk_waterfall_append_iq_device(sdrk_waterfall* wf, sdrk_plan* p, const void
         done += run;
     }
     HIP_TRY(hipStreamSynchronize(wf->stream));
-    return SDRK_OK;
+    return fused_check(p);
 }
 
 int sdrk_waterfall_append_iq(sdrk_waterfall* wf, sdrk_plan* p, const void* iq, size_t n_frames,

@@ -98,9 +98,14 @@ def _features_from_device(ptr, on_device: bool, n_rows: int, nfft: int, freqs, d
             "occupied_bins_20db": (int(s[12]), int(s[13])),
         }
         if f is not None:
-            d["bandwidth_hz_3db"] = float(f[int(s[9])] - f[int(s[8])])               # :169-170
-            d["bandwidth_hz_10db"] = float(f[int(s[11])] - f[int(s[10])])
-            d["bandwidth_hz_20db"] = float(f[int(s[13])] - f[int(s[12])])
+            # an all-NaN row has no bin >= max - x: the kernel returns its empty-range sentinels (first > last)
+            # and the reference's _occupied_bandwidth returns 0.0 for it (classifier.py:166-168)
+            def _bw(lo, hi):
+                lo, hi = int(lo), int(hi)
+                return float(f[hi] - f[lo]) if 0 <= lo <= hi < nfft else 0.0
+            d["bandwidth_hz_3db"] = _bw(s[8], s[9])                                   # :169-170
+            d["bandwidth_hz_10db"] = _bw(s[10], s[11])
+            d["bandwidth_hz_20db"] = _bw(s[12], s[13])
             d["peak_spacing_std_hz"] = float(np.std(np.diff(f[peaks]))) if len(peaks) >= 3 else 0.0  # :214-219
             d["peak_density"] = d["peak_count"] / max(nfft, 1)
         out.append(d)

@@ -113,13 +113,24 @@ def _default_compute(window, eps, shift, device) -> Callable[[np.ndarray], np.nd
     return compute
 
 
+def _local_device(rank: int) -> int:
+    """The GPU this rank owns: LOCAL_RANK (set by torchrun), else the rank, modulo the visible devices."""
+    import os
+
+    import torch
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    d = int(os.environ.get("LOCAL_RANK", rank))
+    return d % n if n > 0 else d
+
+
 def distributed_spectrum_db(samples, *, window=None, eps: float = 1e-12, shift: bool = True,
                             device: Optional[int] = None, dst: int = 0, group=None,
                             compute: Optional[Callable[[np.ndarray], np.ndarray]] = None):
     """One-process-per-GPU form.  Every rank passes the same ``(B, N)`` batch (or a
     lazily-indexable view of it); rank r transforms frames ``rank_range(B, r, W)``
     on its own GPU and rank ``dst`` returns the gathered ``(B, N)`` float32 array
-    (other ranks return ``None``).  ``compute`` replaces the per-rank transform —
+    (other ranks return ``None``).  The rank's GPU is ``device``, else ``LOCAL_RANK`` — it is used for the
+    transform and, under the nccl backend, for the tensor handed to the gather.  ``compute`` replaces the per-rank transform —
     the CPU test-suite injects the oracle there to exercise the sharding and the
     gather under gloo without a GPU; the product default is the HIP path."""
     import torch
@@ -130,10 +141,10 @@ def distributed_spectrum_db(samples, *, window=None, eps: float = 1e-12, shift: 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n_frames, nfft = int(samples.shape[0]), int(samples.shape[1])
     lo, hi = rank_range(n_frames, rank, world)
+    use_cuda = dist.get_backend(group) == "nccl"
+    if device is None and (compute is None or use_cuda):
+        device = _local_device(rank)
     if compute is None:
-        if device is None:
-            import os
-            device = int(os.environ.get("LOCAL_RANK", rank))
         compute = _default_compute(window, eps, shift, device)
     mine = np.ascontiguousarray(samples[lo:hi])
     rows = compute(mine) if hi > lo else np.empty((0, nfft), dtype=np.float32)
@@ -143,10 +154,11 @@ def distributed_spectrum_db(samples, *, window=None, eps: float = 1e-12, shift: 
     longest = max(b - a for a, b in shard_ranges(n_frames, world))
     padded = np.zeros((longest, nfft), dtype=np.float32)
     padded[: hi - lo] = rows
-    use_cuda = dist.get_backend(group) == "nccl"
     t = torch.from_numpy(padded)
     if use_cuda:
-        t = t.cuda()
+        # RCCL moves device tensors: stage on THIS rank's GPU (never torch's current device, which is
+        # cuda:0 in every rank unless the caller ran torch.cuda.set_device)
+        t = t.to(torch.device("cuda", int(device)))
     bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
     dist.gather(t, bucket, dst=dst, group=group)
     if rank != dst:

@@ -32,10 +32,6 @@ from ._ffi import byref, c_float, c_size_t, c_void_p, check, lib
 
 WindowArg = Union[None, str, np.ndarray, Sequence[float]]
 
-# One sdrk_exec_host call stages its whole input on the device; larger host
-# batches are fed through in chunks of about this many input bytes.
-_HOST_CHUNK_BYTES = 256 << 20
-
 
 def _window_spec(window: WindowArg, nfft: int):
     """-> (kind, float32 array or None, cache key)."""
@@ -71,7 +67,7 @@ class SpectrumPlan:
     """
 
     def __init__(self, nfft: int, *, window: WindowArg = None, eps: float = 1e-12,
-                 shift: bool = True, device: int = 0, max_batch: int = 1 << 30):
+                 shift: bool = True, device: int = 0, max_batch: int = 1 << 30, fused64k: bool = False):
         nfft = int(nfft)
         pow2 = nfft >= 2 and not (nfft & (nfft - 1))
         if nfft < 2 or nfft > (1 << _ffi.MAX_LOG2_NFFT) or (not pow2 and nfft > (1 << (_ffi.MAX_LOG2_NFFT - 1))):
@@ -87,8 +83,12 @@ class SpectrumPlan:
         self._lock = threading.Lock()
         self._handle = c_void_p()
         wptr = warr.ctypes.data_as(c_void_p) if warr is not None else None
-        check(lib().sdrk_plan_create(self.device, nfft, c_size_t(int(max_batch)), kind, wptr,
-                                     c_float(self.eps), int(self.shift), byref(self._handle)))
+        # fused64k: the experimental single-launch form of N = 65536; an explicit plan
+        # option, so the path taken is visible in the API and in the plan cache key
+        self.fused64k = bool(fused64k)
+        flags = _ffi.PLAN_FUSED64K if self.fused64k else 0
+        check(lib().sdrk_plan_create_ex(self.device, nfft, c_size_t(int(max_batch)), kind, wptr,
+                                        c_float(self.eps), int(self.shift), flags, byref(self._handle)))
 
     # -- lifetime ---------------------------------------------------------------
     def close(self) -> None:
@@ -116,20 +116,10 @@ class SpectrumPlan:
 
     # -- host arrays ------------------------------------------------------------
     def _run_host(self, fn, iq: np.ndarray, n_frames: int, stride: int, out: np.ndarray) -> None:
-        """Feed `n_frames` frames (start spacing `stride` samples) through `fn` in chunks."""
-        nfft = self.nfft
-        per = max(1, min(_HOST_CHUNK_BYTES // (8 * max(stride, 1)), _HOST_CHUNK_BYTES // (4 * nfft)))
-        flat_in = iq.reshape(-1)
-        flat_out = out.reshape(n_frames, nfft)
+        """One C call for the whole batch: libsdrk cuts it into pinned, pipelined chunks itself."""
         with self._lock:
-            f0 = 0
-            while f0 < n_frames:
-                nf = min(per, n_frames - f0)
-                src = flat_in[f0 * stride:]
-                dst = flat_out[f0:f0 + nf]
-                check(fn(self.handle, src.ctypes.data_as(c_void_p), c_size_t(nf), c_size_t(stride),
-                         dst.ctypes.data_as(c_void_p)))
-                f0 += nf
+            check(fn(self.handle, iq.ctypes.data_as(c_void_p), c_size_t(n_frames), c_size_t(stride),
+                     out.ctypes.data_as(c_void_p)))
 
     def _frames(self, samples):
         x = _as_c64(samples)
@@ -206,6 +196,17 @@ class SpectrumPlan:
         with self._lock:
             check(lib().sdrk_exec_device(self.handle, c_void_p(d_iq), c_size_t(n_frames), c_size_t(stride),
                                          c_void_p(d_out), c_void_p(stream) if stream else None))
+
+    def exec_device_timed_each(self, d_iq: int, n_frames: int, d_out: int, launches: int = 1, *,
+                               frame_stride: Optional[int] = None) -> list:
+        """Like ``exec_device_timed`` but returns the milliseconds of each launch (events between
+        consecutive launches on the plan's stream)."""
+        stride = self.nfft if frame_stride is None else int(frame_stride)
+        ms = (c_float * int(launches))()
+        with self._lock:
+            check(lib().sdrk_exec_device_timed_each(self.handle, c_void_p(d_iq), c_size_t(n_frames),
+                                                    c_size_t(stride), c_void_p(d_out), int(launches), ms))
+        return [float(v) for v in ms]
 
     def exec_device_timed(self, d_iq: int, n_frames: int, d_out: int, launches: int = 1, *,
                           frame_stride: Optional[int] = None) -> float:

@@ -42,7 +42,7 @@ def test_ctypes_table_matches_header():
 def test_version_and_error_string_without_gpu():
     from sdr_iq_visualizer_amd import _ffi
     lib = _ffi.lib()
-    assert lib.sdrk_version() == 100
+    assert lib.sdrk_version() == 200
     assert isinstance(lib.sdrk_last_error(), bytes)
     assert lib.sdrk_device_count() >= 0
 
@@ -81,7 +81,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     exe = _build_c_smoke(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    assert "sdrk 100" in out.stdout
+    assert "sdrk 200" in out.stdout
 
 
 @pytest.mark.gpu

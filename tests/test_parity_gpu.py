@@ -22,6 +22,12 @@ def pkg():
     return p
 
 
+def visible_devices(pkg, at_least=2):
+    """Every GPU the box shows; on a 1-GPU box device 0 repeated, so the threaded paths still run."""
+    n = pkg.device_count()
+    return list(range(n)) if n >= at_least else [0] * at_least
+
+
 def rand_c64(rng, *shape, scale=1.0):
     return ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * scale).astype(np.complex64)
 
@@ -284,6 +290,48 @@ def test_full_size_device_resident_run_properties(pkg):
         lib.sdrk_dev_free(0, d_out)
 
 
+@pytest.mark.parametrize("rank", [0, 5])
+def test_config2_full_size_across_4gib_boundaries(pkg, rank):
+    """BASELINE.json config 2 at its full size — 2^20 frames x 4096, Hann: 32 GiB in, 16 GiB out, the
+    only case whose byte offsets pass 4, 8 and 16 GiB on the N = 4096 kernel — and config 4's per-rank
+    shape (rank g owns frames [g*2^20, (g+1)*2^20): 64-bit frame numbers in the generator).  Frames on
+    both sides of every 4 GiB multiple of the input and output offsets, the ends, and 64 random ones
+    are compared with the oracle on the numpy-regenerated input."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, synth
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    nf, n, seed = 1 << 20, 4096, 1234
+    first = rank * nf
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 8, ctypes.byref(d_in)))
+    try:
+        _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 4, ctypes.byref(d_out)))
+        try:
+            _ffi.check(lib.sdrk_synth_fill(0, seed, first, nf, n, d_in, None))
+            with SpectrumPlan(n, window="hann") as plan:
+                plan.exec_device(d_in.value, nf, d_out.value)
+                plan.sync()
+            edges = set()
+            for gib in (4, 8, 12, 16, 20, 24, 28):
+                for per_frame in (n * 8, n * 4):                       # input and output byte offsets
+                    f = (gib << 30) // per_frame
+                    edges.update(x for x in (f - 1, f, f + 1) if 0 <= x < nf)
+            rng = np.random.default_rng(rank)
+            picks = sorted(edges | {0, 1, nf - 2, nf - 1} | set(int(v) for v in rng.integers(0, nf, 64)))
+            row = np.empty(n, dtype=np.float32)
+            w = np.hanning(n)
+            for f in picks:
+                _ffi.check(lib.sdrk_memcpy_d2h(0, row.ctypes.data_as(ctypes.c_void_p),
+                                               ctypes.c_void_p(d_out.value + f * n * 4), row.nbytes))
+                x = synth.synth_iq(seed, first + f, 1, n)[0]
+                assert_db_parity(row, cpu_ref.spectrum_db(x, window=w), what=f"rank {rank} frame {f}")
+        finally:
+            lib.sdrk_dev_free(0, d_out)
+    finally:
+        lib.sdrk_dev_free(0, d_in)
+
+
 def test_linearity_and_shift_theorem(pkg):
     """Size-independent properties of the transform itself (complex output)."""
     rng = np.random.default_rng(2)
@@ -297,21 +345,35 @@ def test_linearity_and_shift_theorem(pkg):
         assert_complex_parity(Fr, Fa.astype(np.complex128) * np.exp(-2j * np.pi * k / n), rel=2e-5)
 
 
-def test_thread_per_device_sharding_single_gpu(pkg):
-    """sharding.spectrum_db_sharded with the same device listed twice: two threads, two
-    frame ranges, one gathered array (multi-GPU boxes run it with distinct devices)."""
+def test_thread_per_device_sharding_every_visible_gpu(pkg):
+    """sharding.spectrum_db_sharded over every visible GPU (one thread, one frame range, one plan per
+    device; on a 1-GPU box the same device twice): gathered rows equal the single-device path."""
     from sdr_iq_visualizer_amd import sharding
+    devs = visible_devices(pkg)
     rng = np.random.default_rng(4)
     x = rand_c64(rng, 37, 4096, scale=20.0)
-    out = sharding.spectrum_db_sharded(x, [0, 0])
+    out = sharding.spectrum_db_sharded(x, devs)
     assert_db_parity(out, cpu_ref.spectrum_db(x))
     assert np.array_equal(out, pkg.spectrum_db(x, devices=[0]))
     # one long stream split by row ranges with an nfft-hop halo (SURVEY.md §8e)
     stream = rand_c64(rng, 4096 * 9 + 123, scale=5.0)
     whole = pkg.stft_db(stream, 4096, 1024, window="hann")
-    split = pkg.stft_db(stream, 4096, 1024, window="hann", devices=[0, 0, 0])
+    split = pkg.stft_db(stream, 4096, 1024, window="hann", devices=(devs + devs)[:3])
     assert split.shape == whole.shape == (1 + (stream.size - 4096) // 1024, 4096)
     assert np.array_equal(split, whole)
+
+
+@pytest.mark.parametrize("n,batch", [(8192, 9), (16384, 7), (1 << 20, 3)])
+def test_sharding_kernels_with_more_than_64k_lds_on_every_device(pkg, n, batch):
+    """N = 8192 / 16384 (70 / 139 KiB of LDS) and N = 2^20 (col pass 139 KiB) need the dynamic-LDS
+    opt-in on EVERY device they run on (kernels.h ensure_dynamic_lds): shard a batch over all visible
+    GPUs and compare each range with the oracle."""
+    from sdr_iq_visualizer_amd import sharding
+    devs = visible_devices(pkg)
+    rng = np.random.default_rng(n)
+    x = rand_c64(rng, batch, n, scale=3.0)
+    out = sharding.spectrum_db_sharded(x, devs, window="hann")
+    assert_db_parity(out, cpu_ref.spectrum_db(x, window=np.hanning(n)), what=f"N={n} over devices {devs}")
 
 
 # ---- "next" rows (SURVEY.md §8f) on the GPU ------------------------------------------------
@@ -455,7 +517,7 @@ def test_waterfall_decimated_readout(pkg):
     assert np.array_equal(big.as_array(decimate=256), full.reshape(2, 4096, 256).max(-1))
 
 
-def test_fused_n65536_agrees_with_two_launch_path(pkg, monkeypatch):
+def test_fused_n65536_agrees_with_two_launch_path(pkg):
     """The XCD-resident fused kernel (fft_fused64k.hip) does the same arithmetic as the two tiled
     launches (differences: FMA contraction in separately compiled code, i.e. last-bit level); a stale
     or early read of the L2-resident intermediate would be a gross error in a whole tile.
@@ -471,9 +533,7 @@ def test_fused_n65536_agrees_with_two_launch_path(pkg, monkeypatch):
     _ffi.check(lib.sdrk_dev_alloc(0, 2 * nf * n * 4, ctypes.byref(d_b)))
     try:
         _ffi.check(lib.sdrk_synth_fill(0, 77, 0, (nf + 1) * 16, 4096, d_in, None))
-        monkeypatch.setenv("SDRK_FUSED64K", "1")
-        fused = SpectrumPlan(n, window="hann")
-        monkeypatch.setenv("SDRK_FUSED64K", "0")
+        fused = SpectrumPlan(n, window="hann", fused64k=True)
         tiled = SpectrumPlan(n, window="hann")
         a = np.empty(n, dtype=np.float32)
         b = np.empty(n, dtype=np.float32)
@@ -496,24 +556,27 @@ def test_fused_n65536_agrees_with_two_launch_path(pkg, monkeypatch):
 
 
 def test_channel_bank_config5_shape(pkg):
-    """BASELINE.json config 5 in miniature: independent channels (here two, both on GPU 0), N = 2^20,
-    rows appended on the device, decimated host gather; each channel equals the single-channel path."""
+    """BASELINE.json config 5 in miniature: independent channels, one per visible GPU (two on GPU 0 when
+    the box has one), N = 2^20, rows appended on the device, decimated host gather; each channel equals
+    the single-channel path."""
     from sdr_iq_visualizer_amd import synth
     from sdr_iq_visualizer_amd.channels import ChannelBank
     n = 1 << 20
-    bank = ChannelBank(n, [0, 0], maxlen=4, window="hann")
-    chans = [synth.synth_iq(100 + c, 0, 3 * 256, 4096).reshape(3, n) for c in range(2)]
+    devs = visible_devices(pkg)
+    nch = len(devs)
+    bank = ChannelBank(n, devs, maxlen=4, window="hann")
+    chans = [synth.synth_iq(100 + c, 0, 3 * 256, 4096).reshape(3, n) for c in range(nch)]
     bank.append_iq(chans)
     g = bank.gather(decimate=256)
-    assert g.shape == (2, 3, 4096)
-    for c in range(2):
+    assert g.shape == (nch, 3, 4096)
+    for c in range(nch):
         ref = cpu_ref.spectrum_db(chans[c], window=np.hanning(n))
         full = bank.rings[c].as_array()
         assert_db_parity(full, ref, what=f"channel {c}")
         assert np.array_equal(g[c], full.reshape(3, 4096, 256).max(-1))
-    bank.append_iq([chans[0][:1], chans[1]])                     # ragged: channel 0 gets 1 row, channel 1 gets 3
+    bank.append_iq([chans[0][:1]] + chans[1:])                   # ragged: channel 0 gets 1 row, the others 3
     g2 = bank.gather()
-    assert g2.shape == (2, 4, n) and not np.isnan(g2).any()      # both rings are full (maxlen 4)
+    assert g2.shape == (nch, 4, n) and not np.isnan(g2).any()    # every ring is full (maxlen 4)
     bank.close()
 
 

@@ -25,9 +25,18 @@ from sdr_iq_visualizer_amd.spectrum import SpectrumPlan  # noqa: E402
 import sdr_iq_visualizer_amd as pkg  # noqa: E402
 
 
+def link_probe():
+    lib = _ffi.lib()
+    a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _ffi.check(lib.sdrk_host_link_probe(0, 1 << 30, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return {"what": "pinned DMA rates, GB/s (1 GiB up, 0.5 GiB down; duplex quoted on the upstream bytes)",
+            "h2d": round(a.value, 1), "d2h": round(b.value, 1), "duplex_up": round(c.value, 1),
+            "host_helper_threads": int(lib.sdrk_host_threads())}
+
+
 def host_boundary(quick):
     out = []
-    for b in ((1, 4, 256, 4096) if quick else (1, 4, 8, 16, 256, 4096, 32768)):
+    for b in ((1, 4, 256, 4096) if quick else (1, 4, 8, 16, 64, 256, 1024, 4096, 16384, 32768)):
         x = synth.synth_iq(1, 0, b, 4096)
         pkg.spectrum_db(x)                                  # plan + staging warm-up
         reps = 500 if b <= 16 else 5
@@ -36,7 +45,8 @@ def host_boundary(quick):
             pkg.spectrum_db(x)
         dt = (time.perf_counter() - t0) / reps
         out.append({"what": "spectrum_db host->host (PCIe inclusive, pageable numpy)", "batch": b, "nfft": 4096,
-                    "ms_per_call": round(dt * 1e3, 4), "Msamples_per_s": round(b * 4096 / dt / 1e6, 1)})
+                    "ms_per_call": round(dt * 1e3, 4), "Msamples_per_s": round(b * 4096 / dt / 1e6, 1),
+                    "input_GBps": round(b * 4096 * 8 / dt / 1e9, 2)})
     return out
 
 
@@ -76,6 +86,7 @@ def main():
     args = ap.parse_args()
     print(json.dumps({"device": pkg.device_info(0)}))
     if not args.large_only:
+        print(json.dumps(link_probe()), flush=True)
         for r in host_boundary(args.quick):
             print(json.dumps(r), flush=True)
     L = 614_400_000 if not args.quick else 61_440_000
