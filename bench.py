@@ -13,15 +13,26 @@ one rank per GPU; rank g owns frames [g*2^20, (g+1)*2^20) of BASELINE.json confi
 is the barrier and the max-reduce of the elapsed time).
 
 A "step" is one pass of the hot path over the rank's device-resident batch.  Rank 0
-prints ONE JSON line.
+prints ONE JSON line.  At N = 1 the same line also carries:
+  launch_ms            min / median / max of the K timed launches (HIP events between launches)
+  roofline.measured_copy_GBps / frac_of_measured_copy
+                       a no-arithmetic streaming kernel with the same bytes, same buffers, same process
+  telemetry            shader/memory clocks and socket power sampled around and during the timed region
+  cpu_baseline         the oracle on one core, plus `all_cores` (one worker per CPU this process may use)
+  secondary            BASELINE configs 3 and 5 (device resident), the numpy boundary (PCIe inclusive) and
+                       the per-row feature reductions — each with its own algorithmic-bytes formula
+`--no-secondary` skips those extra legs (the driver's N > 1 runs skip them by themselves).
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import glob
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -41,17 +52,21 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=1 << 20, help="frames per GPU (default 2^20)")
     ap.add_argument("--window", default="hann", choices=["hann", "rect"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
-                    help="budget for the numpy cpu_baseline leg (0 disables it)")
-    ap.add_argument("--parity-frames", type=int, default=32)
-    ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="also time the oracle with one forked worker per visible host core (BASELINE.md §3; "
-                         "pure CPU, runs before any GPU runtime is loaded; do not use under rocprofv3)")
+                    help="budget for the single-core numpy cpu_baseline leg (0 disables both CPU legs)")
+    ap.add_argument("--cpu-all-cores-seconds", type=float, default=5.0,
+                    help="budget for the all-cores leg (0 disables it; pure CPU, forked before any GPU runtime loads)")
+    ap.add_argument("--parity-frames", type=int, default=1024,
+                    help="random frames of the timed output checked against the oracle (SURVEY.md §8d: >= 1024)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip configs 3/5, the numpy boundary and the feature-reduction legs")
     return ap.parse_args()
 
 
+# ---- CPU baseline (oracle = checker; a reported number, not the target) -----------------------
+
 def cpu_baseline(window: str, seconds: float):
     """The oracle (oracle/cpu_ref.py, the numpy restatement of streamer.py:119-121) on a
-    bounded sample of the same workload, single host core.  A reported baseline only."""
+    bounded sample of the same workload, single host core."""
     import numpy as np
     from oracle import cpu_ref
     from sdr_iq_visualizer_amd import synth
@@ -82,7 +97,7 @@ def cpu_baseline(window: str, seconds: float):
         "cores": 1,
         "kind": "port",
         "sample": f"{done} frames x {NFFT} ({window}), oracle/cpu_ref.spectrum_db in chunks of {chunk} "
-                  f"for {dt:.1f} s, numpy {np.__version__}, {os.cpu_count()} host cores visible",
+                  f"for {dt:.1f} s, numpy {np.__version__}",
         "per_frame_reference_expression_rect": round(per_frame, 2),
     }
 
@@ -104,22 +119,199 @@ def _cpu_worker(job):
     return done, time.perf_counter() - t0
 
 
+def usable_cpus():
+    """CPUs this process can actually run on at once: the affinity mask capped by the cgroup CPU quota."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else int(txt[0]) / int(txt[1])
+            else:
+                q = int(txt[0])
+                quota = None if q <= 0 else q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    workers = affinity if quota is None else max(1, min(affinity, int(quota)))
+    return workers, affinity, quota
+
+
 def cpu_baseline_all_cores(window: str, seconds: float):
     import multiprocessing as mp
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(1234 + i, window, seconds) for i in range(cores)])
+    workers, affinity, quota = usable_cpus()
+    with mp.get_context("fork").Pool(workers) as pool:
+        res = pool.map(_cpu_worker, [(1234 + i, window, seconds) for i in range(workers)])
     total = sum(r[0] for r in res) * NFFT / max(r[1] for r in res) / 1e6
-    quota = None
+    return {"value": round(total, 1), "unit": "Msamples/s", "cores": workers,
+            "visible_cpus": affinity, "cgroup_cpu_quota": None if quota is None else round(quota, 1),
+            "sample": f"one forked oracle worker per usable CPU for {seconds:.0f} s each, same generator and window"}
+
+
+# ---- clock / power telemetry -----------------------------------------------------------------
+
+class Telemetry:
+    """sysfs readings of the GPU under test (matched by PCI address): current sclk / mclk level and the
+    socket power, before / during / after the timed region.  Everything is best effort: a missing file
+    yields null fields, never an error."""
+
+    def __init__(self, device_info: str):
+        self.dir = None
+        pci = device_info.rsplit("pci ", 1)[-1].strip() if "pci " in device_info else None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                if pci and os.path.basename(os.path.realpath(d)).lower() == pci.lower():
+                    self.dir = d
+                    break
+            except OSError:
+                continue
+        if self.dir is None:
+            cands = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(d + "/pp_dpm_sclk")]
+            self.dir = cands[0] if len(cands) == 1 else None
+        self.hwmon = None
+        if self.dir:
+            h = sorted(glob.glob(self.dir + "/hwmon/hwmon*"))
+            self.hwmon = h[0] if h else None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            return open(path).read()
+        except Exception:
+            return None
+
+    def _dpm(self, name):
+        txt = self._read(f"{self.dir}/{name}") if self.dir else None
+        if not txt:
+            return None
+        for line in txt.splitlines():
+            if line.rstrip().endswith("*"):
+                try:
+                    return int(line.split(":")[1].strip().split("M")[0])
+                except Exception:
+                    return None
+        return None
+
+    def _hw(self, *names):
+        if not self.hwmon:
+            return None
+        for n in names:
+            txt = self._read(f"{self.hwmon}/{n}")
+            if txt:
+                try:
+                    return int(txt.strip())
+                except ValueError:
+                    continue
+        return None
+
+    def snapshot(self):
+        sclk_hz = self._hw("freq1_input")
+        p = self._hw("power1_average", "power1_input")
+        return {"sclk_mhz": self._dpm("pp_dpm_sclk") if sclk_hz is None else round(sclk_hz / 1e6),
+                "mclk_mhz": self._dpm("pp_dpm_mclk"), "fclk_mhz": self._dpm("pp_dpm_fclk"),
+                "power_w": None if p is None else round(p / 1e6, 1)}
+
+    def start(self, period=0.002):
+        if not self.dir:
+            return
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append(self.snapshot())
+                time.sleep(period)
+
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread:
+            self._thread.join()
+
+    def summary(self):
+        def agg(key):
+            v = [s[key] for s in self.samples if s.get(key) is not None]
+            return None if not v else {"min": min(v), "mean": round(sum(v) / len(v), 1), "max": max(v)}
+        return {"n": len(self.samples), "sclk_mhz": agg("sclk_mhz"), "mclk_mhz": agg("mclk_mhz"),
+                "power_w": agg("power_w")}
+
+
+# ---- secondary workloads (rank 0, N = 1) ---------------------------------------------------------
+
+def _median(v):
+    return float(statistics.median(v))
+
+
+def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, reps):
+    """A device-resident run of one large-frame configuration: median launch time over `reps`."""
+    in_samples = (n_frames - 1) * stride + nfft
+    gen_frames = (in_samples + 4095) // 4096
+    d_gen, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(dev, gen_frames * 4096 * 8, ctypes.byref(d_gen)))
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q == "max" else round(int(q) / int(per), 1)
-    except Exception:
-        pass
-    return {"value": round(total, 1), "unit": "Msamples/s", "workers": cores, "cgroup_cpu_quota": quota}
+        _ffi.check(lib.sdrk_dev_alloc(dev, n_frames * nfft * 4, ctypes.byref(d_out)))
+        try:
+            _ffi.check(lib.sdrk_synth_fill(dev, 99, 0, gen_frames, 4096, d_gen, None))
+            with SpectrumPlan(nfft, window=window, device=dev) as plan:
+                plan.exec_device(d_gen.value, n_frames, d_out.value, frame_stride=stride)
+                plan.sync()
+                ms = plan.exec_device_timed_each(d_gen.value, n_frames, d_out.value, reps, frame_stride=stride)
+        finally:
+            lib.sdrk_dev_free(dev, d_out)
+    finally:
+        lib.sdrk_dev_free(dev, d_gen)
+    t = _median(ms) * 1e-3
+    algo = 8 * in_samples + 4 * n_frames * nfft        # unique input once + rows once (SURVEY.md §8d)
+    return {"nfft": nfft, "frames": n_frames, "hop": stride, "window": window or "rect",
+            "ms": round(t * 1e3, 3), "ms_min": round(min(ms), 3), "ms_max": round(max(ms), 3),
+            "input_Msamples_per_s": round(in_samples / t / 1e6, 1),
+            "frame_Msamples_per_s": round(n_frames * nfft / t / 1e6, 1),
+            "algorithmic_bytes": algo, "algorithmic_formula": "8*L + 4*rows*N",
+            "GBps": round(algo / t / 1e9, 1), "frac": round(algo / t / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
+def numpy_boundary(lib, _ffi, pkg, synth, dev):
+    """spectrum_db(host array) -> host array, PCIe and staging inclusive (never `value`)."""
+    import numpy as np
+    a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _ffi.check(lib.sdrk_host_link_probe(dev, 1 << 30, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    out = {"what": "pkg.spectrum_db(complex64 numpy (B,4096)) -> float32 numpy, pageable arrays, N=4096 rect",
+           "link_probe_GBps": {"h2d": round(a.value, 1), "d2h": round(b.value, 1), "duplex_upstream": round(c.value, 1)},
+           "host_helper_threads": int(lib.sdrk_host_threads()), "by_batch": {}}
+    for bsz in (1, 16, 256, 4096, 32768):
+        x = synth.synth_iq(1, 0, bsz, NFFT)
+        one = x[0] if bsz == 1 else x
+        pkg.spectrum_db(one, device=dev)                        # plan + staging warm-up
+        reps = 300 if bsz <= 16 else (9 if bsz <= 4096 else 3)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            y = pkg.spectrum_db(one, device=dev)
+            ts.append(time.perf_counter() - t0)
+            del y                                               # the free is the caller's cost, not the call's
+        rec = {"ms_per_call": round(_median(ts) * 1e3, 4),
+               "Msamples_per_s": round(bsz * NFFT / _median(ts) / 1e6, 1),
+               "input_GBps": round(bsz * NFFT * 8 / _median(ts) / 1e9, 2)}
+        if bsz >= 256:                                          # result array reused by the caller (out=)
+            res = np.empty((bsz, NFFT), dtype=np.float32)
+            pkg.spectrum_db(x, device=dev, out=res)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                pkg.spectrum_db(x, device=dev, out=res)
+                ts.append(time.perf_counter() - t0)
+            rec["reused_out_ms_per_call"] = round(_median(ts) * 1e3, 4)
+            rec["reused_out_input_GBps"] = round(bsz * NFFT * 8 / _median(ts) / 1e9, 2)
+            rec["reused_out_frac_of_duplex_link"] = round(bsz * NFFT * 8 / _median(ts) / 1e9 / c.value, 3)
+        out["by_batch"][f"B{bsz}"] = rec
+    return out
 
 
 def main():
@@ -132,17 +324,19 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run "
                      "--nproc-per-node N (one rank per GPU)")
         args.gpus = world
+    solo = rank == 0 and world == 1
 
     # cpu baseline first: plain numpy, before any GPU runtime is up (rank 0, N=1 only)
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if solo and args.cpu_seconds > 0:
         cpu = cpu_baseline(args.window, args.cpu_seconds)
-        if args.cpu_all_cores:
-            cpu["all_cores"] = cpu_baseline_all_cores(args.window, min(args.cpu_seconds, 5.0))
+        if args.cpu_all_cores_seconds > 0:
+            cpu["all_cores"] = cpu_baseline_all_cores(args.window, args.cpu_all_cores_seconds)
 
     import torch  # before libsdrk: one shared HIP runtime in the process (see _ffi.py)
     import numpy as np
     from oracle import cpu_ref
+    import sdr_iq_visualizer_amd as pkg
     from sdr_iq_visualizer_amd import _ffi, synth
     from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
 
@@ -162,6 +356,8 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
     lib = _ffi.lib()
     _ffi.require_device(dev)
+    info = _ffi.device_info(dev)
+    tel = Telemetry(info) if rank == 0 else None
 
     frames = args.frames
     first_frame = rank * frames                     # config 4: GPU g owns [g*F, (g+1)*F)
@@ -181,18 +377,25 @@ def main():
     for _ in range(args.warmup):
         plan.exec_device(d_in.value, frames, d_out.value)
     barrier()
+    before = tel.snapshot() if tel else None
+    if tel:
+        tel.start()
     t0 = time.perf_counter()
-    # K steps, bracketed by HIP events on the stream the kernel runs on
-    kernel_ms = plan.exec_device_timed(d_in.value, frames, d_out.value, launches=args.steps)
+    # K steps; HIP events on the stream the kernel runs on, one between every two launches
+    each_ms = plan.exec_device_timed_each(d_in.value, frames, d_out.value, launches=args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if tel:
+        tel.stop()
+    after = tel.snapshot() if tel else None
+    kernel_ms = float(sum(each_ms))
     if dist is not None:
         t = torch.tensor([elapsed, kernel_ms], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    # parity spot check on this rank's output (oracle = checker only)
-    parity = 0.0
+    # parity on this rank's output of the timed launches (oracle = checker only)
+    parity, n_checked = 0.0, 0
     if args.parity_frames > 0:
         rng = np.random.default_rng(rank)
         picks = np.unique(np.concatenate([[0, frames - 1], rng.integers(0, frames, args.parity_frames)]))
@@ -204,15 +407,44 @@ def main():
             ref = cpu_ref.spectrum_db(synth.synth_iq(1234, first_frame + int(f), 1, NFFT)[0], window=w)
             mg, mr = 10.0 ** (row.astype(np.float64) / 20), 10.0 ** (ref.astype(np.float64) / 20)
             parity = max(parity, float(np.abs(mg - mr).max() / mr.max()))
+        n_checked = int(picks.size)
     if dist is not None:
         t = torch.tensor([parity], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         parity = float(t[0])
 
-    info = _ffi.device_info(dev)
+    # the same bytes with no arithmetic, same buffers, same process: the measured-copy ceiling (rank 0)
+    copy_gbps = None
+    if rank == 0:
+        try:
+            ms = (ctypes.c_float * 10)()
+            _ffi.check(lib.sdrk_stream_ceiling_probe(dev, d_in, d_out, frames, 10, ms))
+            copy_gbps = ALGO_BYTES_PER_SAMPLE * frames * NFFT / (_median(list(ms)) * 1e-3) / 1e9
+        except Exception as e:                                   # a probe must never cost the bench line
+            copy_gbps = None
+            print(f"[bench] stream ceiling probe failed: {e}", file=sys.stderr)
+
     plan.close()
     lib.sdrk_dev_free(dev, d_in)
     lib.sdrk_dev_free(dev, d_out)
+
+    secondary = None
+    if solo and not args.no_secondary:
+        secondary = {}
+        try:
+            L = 614_400_000                                       # 10 s @ 61.44 Msps
+            r = device_config(lib, _ffi, SpectrumPlan, dev, 65536, 1 + (L - 65536) // 32768, 32768, "hann", 7)
+            r["realtime_factor_at_61.44_Msps"] = round(10.0 / (r["ms"] * 1e-3), 1)
+            r["workload"] = "BASELINE.json configs[2]: waterfall STFT N=65536, 50 % overlap, 10 s @ 61.44 Msps"
+            r["kernels"] = "sdrk::col_pass_kernel<8> + sdrk::row_pass_kernel<8> per 256-frame chunk"
+            secondary["config3"] = r
+            r = device_config(lib, _ffi, SpectrumPlan, dev, 1 << 20, 256, 1 << 20, "hann", 7)
+            r["workload"] = "BASELINE.json configs[4], one channel: 256 back-to-back N=2^20 frames"
+            r["realtime_factor_at_61.44_Msps"] = round((256 * (1 << 20) / 61.44e6) / (r["ms"] * 1e-3), 1)
+            secondary["config5_one_channel"] = r
+            secondary["numpy_boundary"] = numpy_boundary(lib, _ffi, pkg, synth, dev)
+        except Exception as e:
+            secondary["error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0:
         samples_per_step = frames * NFFT * world
@@ -220,13 +452,15 @@ def main():
         value = samples_per_step / (elapsed / args.steps) / 1e6
         launch_ms = kernel_ms / args.steps
         achieved = ALGO_BYTES_PER_SAMPLE * frames * NFFT / (launch_ms * 1e-3) / 1e9   # per GPU
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):                    # PMC-derived bytes per launch, see profiles/README.md
             try:
                 rec = json.load(open(tpath))
                 if rec.get("frames") == frames and rec.get("window") == args.window:
                     traffic = rec.get("bytes_per_launch")
+                    traffic_src = ("profiles/hbm_traffic.json: a SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run "
+                                   "of this command (not measured by this run)")
             except Exception:
                 traffic = None
         line = {
@@ -258,14 +492,28 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "sdrk::fft4096_kernel",
                 "kernel_ms_per_launch": round(launch_ms, 4),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * frames * NFFT,
+                "measured_copy_GBps": None if copy_gbps is None else round(copy_gbps, 1),
+                "frac_of_measured_copy": None if not copy_gbps else round(achieved / copy_gbps, 4),
+                "measured_copy_what": "sdrk_stream_ceiling_probe: 32 KiB read + 16 KiB written per frame, no arithmetic, "
+                                      "same buffers, median of 10 launches after the timed region",
             },
+            "launch_ms": {"min": round(min(each_ms), 4), "median": round(_median(each_ms), 4),
+                          "max": round(max(each_ms), 4), "mean": round(sum(each_ms) / len(each_ms), 4),
+                          "n": len(each_ms), "scope": "rank 0"},
             "parity_max_rel_err": parity,
+            "parity_frames_checked": n_checked,
         }
+        if tel is not None:
+            line["telemetry"] = {"before": before, "during": tel.summary(), "after": after,
+                                 "source": tel.dir or "no sysfs node found for this device"}
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if secondary is not None:
+            line["secondary"] = secondary
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

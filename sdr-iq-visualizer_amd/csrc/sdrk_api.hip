@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -125,6 +126,7 @@ struct sdrk_plan {
 };
 constexpr size_t SMALL_IN_BYTES = 256 << 10;   // calls up to this much input take the zero-copy path
 constexpr size_t HOST_CHUNK_BYTES = 16 << 20;  // target input bytes per pipelined chunk of sdrk_exec_host
+constexpr size_t ZERO_COPY_MAX_BYTES = 32 << 20;  // calls up to this much input skip the DMA engines (see exec_host_common)
 constexpr unsigned FUSED_MAILBOX = 64;   // entries of 8 words: error flag + debug record
 constexpr size_t FUSED_PIECE = 1u << 16;  // frames per fused launch (sizes the control block once, at plan creation)
 
@@ -293,12 +295,21 @@ int slot_reserve(sdrk_plan* p, HostSlot& s, size_t in_bytes, size_t out_bytes) {
     return SDRK_OK;
 }
 
+struct HostTrace {   // SDRK_HOST_TRACE=1: where a pipelined sdrk_exec_host call spends its wall time (stderr)
+    bool on = false;
+    double t_in = 0, t_wait = 0, t_out = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+
 // Wait for the chunk in flight in slot `s` and hand its rows to the caller's array.
-int slot_retire(HostSlot& s) {
+int slot_retire(HostSlot& s, HostTrace& tr) {
     if (!s.busy) return SDRK_OK;
     s.busy = false;
+    const double t0 = tr.on ? HostTrace::now() : 0;
     HIP_TRY(hipEventSynchronize(s.ev_done));
+    const double t1 = tr.on ? HostTrace::now() : 0;
     sdrk::CopyPool::get().copy(s.user_out, s.h_out, s.out_bytes);
+    if (tr.on) { tr.t_wait += t1 - t0; tr.t_out += HostTrace::now() - t1; }
     return SDRK_OK;
 }
 
@@ -359,27 +370,47 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
     const size_t chunk_in = ((per - 1) * frame_stride + nfft) * sizeof(float2);
     const size_t chunk_out = per * nfft * out_elem;
     sdrk::CopyPool& pool = sdrk::CopyPool::get();
+    HostTrace tr;
+    { const char* env = getenv("SDRK_HOST_TRACE"); tr.on = env && env[0] == '1'; }
+    // Mid-size calls of packed frames on the single-pass kernels: let the transform read the pinned chunk and
+    // write the pinned rows itself over PCIe (measured on MI355X, N = 4096: B = 16 48 vs 81 us, B = 256 0.34 vs
+    // 0.44 ms against the DMA form; equal at 32 MiB).  Large calls, overlapped frames (the halo would cross PCIe
+    // twice) and the two-pass kernels (their 128-byte column segments read host memory at half the DMA rate:
+    // 26 vs 48 GB/s at N = 65536) use the copy engines.
+    const bool zero_copy = p->nfft <= 16384 && !p->blu_inner && frame_stride >= nfft && in_bytes <= ZERO_COPY_MAX_BYTES;
+    const double t_call = tr.on ? HostTrace::now() : 0;
     size_t c = 0;
     for (size_t f0 = 0; f0 < n_frames; f0 += per, ++c) {
         HostSlot& s = p->slot[c % HOST_SLOTS];
         const size_t nf = n_frames - f0 < per ? n_frames - f0 : per;
         const size_t cin = ((nf - 1) * frame_stride + nfft) * sizeof(float2);
         const size_t cout = nf * nfft * out_elem;
-        st = slot_retire(s);                                   // chunk c - HOST_SLOTS: rows out, slot free
+        st = slot_retire(s, tr);                               // chunk c - HOST_SLOTS: rows out, slot free
         if (st == SDRK_OK) st = slot_reserve(p, s, chunk_in, chunk_out);
         if (st != SDRK_OK) { slots_abandon(p); return st; }
+        const double t0 = tr.on ? HostTrace::now() : 0;
         pool.copy(s.h_in, static_cast<const float2*>(iq) + f0 * frame_stride, cin);
-        hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, cin, hipMemcpyHostToDevice, p->s_h2d);
-        if (e == hipSuccess) e = hipEventRecord(s.ev_in, p->s_h2d);
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, s.ev_in, 0);
-        if (e == hipSuccess) {
-            st = plan_launch(p, s.d_in, nf, frame_stride, s.d_out, epilogue, p->stream);
+        if (tr.on) tr.t_in += HostTrace::now() - t0;
+        hipError_t e = hipSuccess;
+        if (zero_copy) {
+            // the transform reads the pinned chunk and writes the pinned rows itself, over PCIe: no DMA-engine
+            // copies, two API calls per chunk
+            st = plan_launch(p, s.h_in, nf, frame_stride, s.h_out, epilogue, p->stream);
             if (st != SDRK_OK) { slots_abandon(p); return st; }
-            e = hipEventRecord(s.ev_k, p->stream);
+            e = hipEventRecord(s.ev_done, p->stream);
+        } else {
+            e = hipMemcpyAsync(s.d_in, s.h_in, cin, hipMemcpyHostToDevice, p->s_h2d);
+            if (e == hipSuccess) e = hipEventRecord(s.ev_in, p->s_h2d);
+            if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, s.ev_in, 0);
+            if (e == hipSuccess) {
+                st = plan_launch(p, s.d_in, nf, frame_stride, s.d_out, epilogue, p->stream);
+                if (st != SDRK_OK) { slots_abandon(p); return st; }
+                e = hipEventRecord(s.ev_k, p->stream);
+            }
+            if (e == hipSuccess) e = hipStreamWaitEvent(p->s_d2h, s.ev_k, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(s.h_out, s.d_out, cout, hipMemcpyDeviceToHost, p->s_d2h);
+            if (e == hipSuccess) e = hipEventRecord(s.ev_done, p->s_d2h);
         }
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->s_d2h, s.ev_k, 0);
-        if (e == hipSuccess) e = hipMemcpyAsync(s.h_out, s.d_out, cout, hipMemcpyDeviceToHost, p->s_d2h);
-        if (e == hipSuccess) e = hipEventRecord(s.ev_done, p->s_d2h);
         if (e != hipSuccess) {
             slots_abandon(p);
             return fail(SDRK_ERR_HIP, "host pipeline failed: %s", hipGetErrorString(e));
@@ -389,8 +420,15 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
         s.out_bytes = cout;
     }
     for (size_t i = 0; i < HOST_SLOTS; ++i) {                  // drain in submission order
-        st = slot_retire(p->slot[(c + i) % HOST_SLOTS]);
+        st = slot_retire(p->slot[(c + i) % HOST_SLOTS], tr);
         if (st != SDRK_OK) { slots_abandon(p); return st; }
+    }
+    if (tr.on) {
+        const double t = HostTrace::now() - t_call;
+        fprintf(stderr, "[sdrk host] %zu chunks of %zu frames, %.1f MiB in: total %.3f ms = stage-in %.3f + wait %.3f + "
+                "stage-out %.3f + other %.3f (%.1f GB/s of input, %d helper threads)\n", c, per,
+                in_bytes / 1048576.0, t * 1e3, tr.t_in * 1e3, tr.t_wait * 1e3, tr.t_out * 1e3,
+                (t - tr.t_in - tr.t_wait - tr.t_out) * 1e3, in_bytes / t / 1e9, pool.helpers());
     }
     return fused_check(p);
 }
@@ -418,9 +456,9 @@ int sdrk_device_info(int device, char* buf, size_t buf_len) {
     if (st != SDRK_OK) return st;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    snprintf(buf, buf_len, "%s %s, %d CUs, %.1f GiB, %d MHz", prop.gcnArchName, prop.name,
+    snprintf(buf, buf_len, "%s %s, %d CUs, %.1f GiB, %d MHz, pci %04x:%02x:%02x.0", prop.gcnArchName, prop.name,
              prop.multiProcessorCount, (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0),
-             prop.clockRate / 1000);
+             prop.clockRate / 1000, prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
     return SDRK_OK;
 }
 

@@ -45,21 +45,23 @@ def rank_range(n_frames: int, rank: int, world_size: int) -> Tuple[int, int]:
 
 
 def spectrum_db_sharded(samples, devices: Sequence[int], *, window=None, eps: float = 1e-12,
-                        shift: bool = True) -> np.ndarray:
-    """``spectrum_db`` of a ``(B, N)`` batch split over ``devices`` by frame range."""
-    from .spectrum import _as_c64, _cached_plan
+                        shift: bool = True, out: Optional[np.ndarray] = None) -> np.ndarray:
+    """``spectrum_db`` of a ``(B, N)`` batch split over ``devices`` by frame range.  Each device's thread
+    drives its own plan — its own pinned pipeline (sdrk_exec_host) — and writes its rows straight into its
+    slice of the one result array (``out`` if given)."""
+    from .spectrum import SpectrumPlan, _as_c64, _cached_plan
 
     x = _as_c64(samples)
     if x.ndim != 2:
         raise ValueError("sharding needs a (B, N) batch")
-    out = np.empty(x.shape, dtype=np.float32)
+    out = SpectrumPlan._out_array(out, x.shape, np.float32)
     ranges = shard_ranges(x.shape[0], len(devices))
     errors: List[BaseException] = []
 
     def work(dev: int, lo: int, hi: int) -> None:
         try:
             if hi > lo:
-                out[lo:hi] = _cached_plan(x.shape[1], window, eps, shift, dev).spectrum_db(x[lo:hi])
+                _cached_plan(x.shape[1], window, eps, shift, dev).spectrum_db(x[lo:hi], out=out[lo:hi])
         except BaseException as e:  # surfaced on the calling thread below
             errors.append(e)
 

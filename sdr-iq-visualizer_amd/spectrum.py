@@ -131,13 +131,24 @@ class SpectrumPlan:
             raise ValueError(f"expected shape ({self.nfft},) or (B, {self.nfft}), got {x.shape}")
         return x, False
 
-    def spectrum_db(self, samples) -> np.ndarray:
-        """float32 ``20*log10(|fftshift(fft(w*x))| + eps)`` for one frame or a batch."""
+    @staticmethod
+    def _out_array(out, shape, dtype) -> np.ndarray:
+        """A caller-provided result array (reused across calls: no page faults on fresh memory, no munmap of
+        the previous result — at 256 MiB those cost as much as the transfer) or a new one."""
+        if out is None:
+            return np.empty(shape, dtype=dtype)
+        if not isinstance(out, np.ndarray) or out.dtype != dtype or out.shape != tuple(shape) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of shape {tuple(shape)}")
+        return out
+
+    def spectrum_db(self, samples, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """float32 ``20*log10(|fftshift(fft(w*x))| + eps)`` for one frame or a batch; ``out`` (same shape as
+        ``samples``, float32) receives the rows in place when given."""
         x, one = self._frames(samples)
-        out = np.empty(x.shape, dtype=np.float32)
+        res = self._out_array(out, x.shape[1:] if one else x.shape, np.float32)
         if x.shape[0]:
-            self._run_host(lib().sdrk_exec_host, x, x.shape[0], self.nfft, out)
-        return out[0] if one else out
+            self._run_host(lib().sdrk_exec_host, x, x.shape[0], self.nfft, res)
+        return res
 
     def fft(self, samples) -> np.ndarray:
         """complex64 spectrum ``fft(w*x)`` (fftshifted if the plan shifts), no log."""
@@ -147,7 +158,7 @@ class SpectrumPlan:
             self._run_host(lib().sdrk_exec_fft_host, x, x.shape[0], self.nfft, out)
         return out[0] if one else out
 
-    def stft_db(self, iq, hop: Optional[int] = None) -> np.ndarray:
+    def stft_db(self, iq, hop: Optional[int] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Rows of a spectrogram over one contiguous stream: row r covers samples
         ``[r*hop, r*hop + nfft)``; ``rows = 1 + (len(iq) - nfft) // hop`` (0 if the
         stream is shorter than one frame).  Frames are cut on the device from the
@@ -157,7 +168,7 @@ class SpectrumPlan:
         if hop < 1:
             raise ValueError("hop must be >= 1")
         rows = 0 if x.shape[0] < self.nfft else 1 + (x.shape[0] - self.nfft) // hop
-        out = np.empty((rows, self.nfft), dtype=np.float32)
+        out = self._out_array(out, (rows, self.nfft), np.float32)
         if rows:
             self._run_host(lib().sdrk_exec_host, x, rows, hop, out)
         return out
@@ -254,22 +265,25 @@ def _nfft_of(samples) -> int:
 
 
 def spectrum_db(samples, *, window: WindowArg = None, eps: float = 1e-12, shift: bool = True,
-                device: int = 0, devices: Optional[Sequence[int]] = None) -> np.ndarray:
+                device: int = 0, devices: Optional[Sequence[int]] = None,
+                out: Optional[np.ndarray] = None) -> np.ndarray:
     """Power spectrum in dB of one frame ``(N,)`` or a batch ``(B, N)`` of complex IQ.
 
     Equivalent to ``20*np.log10(np.abs(np.fft.fftshift(np.fft.fft(samples*window, axis=-1),
     axes=-1)) + eps)`` in float32 — with the defaults, exactly the reference's
     ``power_db`` (app/sdr/streamer.py:119,121).  ``devices=[0,1,...]`` splits a
     batch into contiguous frame ranges, one per GPU (no collectives; see
-    sharding.py).
+    sharding.py).  ``out``: a float32 array of the result's shape to fill instead of
+    allocating (large batches: reusing it saves the page faults and the munmap of a
+    fresh result per call).
     """
     nfft = _nfft_of(samples)
     if devices is not None and len(devices) > 1 and np.ndim(samples) == 2:
         from .sharding import spectrum_db_sharded
-        return spectrum_db_sharded(samples, devices, window=window, eps=eps, shift=shift)
+        return spectrum_db_sharded(samples, devices, window=window, eps=eps, shift=shift, out=out)
     if devices is not None and len(devices) == 1:
         device = devices[0]
-    return _cached_plan(nfft, window, eps, shift, device).spectrum_db(samples)
+    return _cached_plan(nfft, window, eps, shift, device).spectrum_db(samples, out=out)
 
 
 def fft_c64(samples, *, window: WindowArg = None, shift: bool = False, device: int = 0) -> np.ndarray:

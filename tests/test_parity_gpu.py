@@ -237,6 +237,42 @@ def test_waterfall_append_iq_on_device(pkg):
 
 # ---- device generator -----------------------------------------------------------------
 
+def test_host_pipeline_chunking_paths(pkg):
+    """sdrk_exec_host beyond the single-chunk sizes: the zero-copy form (packed N <= 16384 frames, <= 32 MiB:
+    kernel reads/writes pinned chunks), the DMA form (larger calls, overlapped frames, two-pass kernels), ragged
+    last chunks, a reused ``out=`` array, complex output — each against the oracle or the one-frame path."""
+    from sdr_iq_visualizer_amd import synth
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    # zero-copy, 4 chunks with a ragged tail; then the same plan through the DMA form (5 x 16 MiB + tail)
+    x = synth.synth_iq(11, 0, 2700, 4096)
+    out = np.full((2700, 4096), np.nan, dtype=np.float32)
+    with SpectrumPlan(4096, window="hann") as plan:
+        got = plan.spectrum_db(x[:601], out=out[:601])
+        assert got is not None and np.shares_memory(got, out)
+        plan.spectrum_db(x, out=out)                                   # reuse: every row rewritten
+        singles = np.stack([plan.spectrum_db(x[f]) for f in (0, 600, 601, 2047, 2048, 2699)])
+    ref_rows = (0, 600, 601, 2047, 2048, 2699)
+    assert np.array_equal(out[list(ref_rows)], singles)
+    assert_db_parity(out[::97], cpu_ref.spectrum_db(x[::97], window=np.hanning(4096)))
+    assert not np.isnan(out).any()
+    with pytest.raises(ValueError):
+        pkg.spectrum_db(x[:4], out=np.empty((4, 4096), dtype=np.float64))
+    # overlapped frames cut from one stream (DMA form; chunks re-send only their nfft-hop halo)
+    stream = synth.synth_iq(12, 0, 1500, 4096).reshape(-1)
+    rows = pkg.stft_db(stream, 8192, 2048, window="hann")
+    assert rows.shape == (1 + (stream.size - 8192) // 2048, 8192)
+    pick = [0, 1, 511, 512, 1023, rows.shape[0] - 1]
+    frames = np.stack([stream[r * 2048: r * 2048 + 8192] for r in pick])
+    assert_db_parity(rows[pick], cpu_ref.spectrum_db(frames, window=np.hanning(8192)))
+    # two-pass kernel, several chunks of 32 frames + a tail
+    y = synth.synth_iq(13, 0, 70 * 16, 4096).reshape(70, 65536)
+    z = pkg.spectrum_db(y)
+    assert_db_parity(z[[0, 31, 32, 63, 64, 69]], cpu_ref.spectrum_db(y[[0, 31, 32, 63, 64, 69]]))
+    # complex output through the same pipeline
+    c = pkg.fft_c64(x[:700])
+    assert_complex_parity(c[[0, 255, 256, 699]], np.fft.fft(x[[0, 255, 256, 699]].astype(np.complex128), axis=-1), rel=1e-5)
+
+
 def test_device_generator_bit_identical_to_numpy_mirror(pkg):
     import ctypes
     from sdr_iq_visualizer_amd import _ffi, synth
