@@ -33,7 +33,8 @@ MAX_LOG2_NFFT = 22
 PLAN_FUSED64K = 0x1
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_PKG_DIR, "lib", "libsdrk.so")
+# SDRK_LIB: developer override (A/B builds made by tools/variant.sh); the product loads lib/libsdrk.so
+_LIB_PATH = os.environ.get("SDRK_LIB") or os.path.join(_PKG_DIR, "lib", "libsdrk.so")
 
 
 class SdrkError(RuntimeError):

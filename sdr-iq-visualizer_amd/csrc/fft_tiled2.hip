@@ -18,8 +18,37 @@
 
 namespace sdrk {
 
-// W = tile width in columns (16, or 8 for A = 1024 so that two 512-thread workgroups fit a CU)
-template <int LOG2A, bool HAS_WINDOW, int W>
+// Scratch layout between the passes.  The col pass produces, per workgroup, all A values of k3 for W adjacent
+// m; the row pass consumes 16 adjacent k3 for all M values of m: whatever the layout, the two footprints meet
+// in 16 x 16 element squares.  Stored as [k3/16][m/16][k3%16][m%16] (2 KiB squares, row tiles contiguous)
+// the col pass writes 2 KiB runs (512 B per wave instruction) instead of the 128-byte pieces at M*8-byte
+// stride a plain [k3][m] matrix costs it, and the row pass reads its 16 x M tile as one contiguous block.
+#ifndef T2_BLOCKED
+#define T2_BLOCKED 1
+#endif
+#ifndef T2_ST_AUX
+#define T2_ST_AUX 0   // cache policy of the scratch stores (0 default, 2 nt)
+#endif
+// element index of (k3, m) inside one frame's scratch
+__device__ __forceinline__ int scratch_index(int k3, int m, int M) {
+#if T2_BLOCKED
+    return (((k3 >> 4) * (M >> 4) + (m >> 4)) << 8) + ((k3 & 15) << 4) + (m & 15);
+#else
+    return k3 * M + m;
+#endif
+}
+
+// W = tile width in columns (16, or 8 for A = 2048 so that the tile fits the LDS).
+// FIXED: the grid is a multiple of the tiles per frame, so every workgroup keeps the same tile position (same
+// m) for all its frames.  Its window coefficients and its W_N^(m k3) factors are then loop invariants held in
+// registers, and the kernel runs a software pipeline: the next tile's 16 loads per thread are issued before the
+// current tile's passes and stay in flight across its barriers, so that the load latency, the transform and the
+// scratch stores of consecutive tiles overlap inside ONE workgroup instead of relying on the co-resident
+// workgroups being in different phases (measured on config 3: the col pass alone takes 2.3 ms without its
+// stores, 2.4 ms without its loads and 3.8 ms with both — serialised phases).  Nothing in the loop body other
+// than the stream itself touches vector memory: vmcnt counts loads and stores in issue order on gfx950, so any
+// table load issued after the stores would make the wave wait for the store acknowledgements.
+template <int LOG2A, bool HAS_WINDOW, int W, bool FIXED>
 __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 ? 4 : 3)) void col_pass_kernel(
     const float2* __restrict__ iq, size_t frame_stride, float2* __restrict__ scratch, size_t n_frames, int M,
     const float* __restrict__ window, const float2* __restrict__ twA, const float2* __restrict__ t1T,
@@ -34,61 +63,121 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     const size_t nfft = (size_t)A * M;
     const int tiles = M / W;
     const size_t items = n_frames * (size_t)tiles;
+    const int estep = T * M;             // n3 += T
 
-    // With the grid a multiple of the tiles per frame every workgroup keeps the same tile position for all
-    // its frames, so its 16 window coefficients per thread are loop invariants: keep them in registers
-    // (saves the 4 B/sample of L2 traffic the window costs; not at 1024 threads, where VGPRs are capped at 128).
-    constexpr bool WIN_REGS = HAS_WINDOW && (C::T * W <= 512);
-    const bool fixed_tile = WIN_REGS && (gridDim.x % tiles) == 0 && W >= 16;
-    float wreg[16];
-    if (WIN_REGS && fixed_tile) {
-        const int m_fixed = (int)(blockIdx.x % tiles) * W + fr;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wreg[q] = window[(size_t)(tau + T * q) * M + m_fixed];
-    }
-
-    for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
+    // tile (frame f, columns m .. ) of work item g
+    auto locate = [&](size_t g, size_t& f, int& m) {
         // W == 8: the two tiles that share each 128-byte line go to blocks b and b+8 (same XCD under the
         // round-robin placement; a speed hint only)
         size_t it = g;
         if (W == 8 && (items & 15) == 0) it = (g & ~(size_t)15) + ((g & 7) << 1) + ((g >> 3) & 1);
-        const size_t f = it / tiles;
-        const int m = (int)(it - f * tiles) * W + fr;
-        // buffer addressing: wave-uniform descriptor on the frame, one 32-bit lane offset, uniform row steps
-        const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + f * frame_stride, (unsigned)(nfft * 8));
-        const __amdgpu_buffer_rsrc_t rw = frame_rsrc(window, HAS_WINDOW ? (unsigned)(nfft * 4) : 0u);
-        const int e0 = tau * M + m;          // element (n3 = tau, m)
-        const int estep = T * M;             // n3 += T
-        cf v[16];
-#pragma unroll
-        for (int i = 0; i < C0; ++i)
-#pragma unroll
-            for (int j = 0; j < R0; ++j) {
-                const int q = i + C0 * j;
-                v2f t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, 2));
-                if (HAS_WINDOW) {
-                    float w;
-                    if (WIN_REGS && fixed_tile) w = wreg[q];
-                    else w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, e0 * 4, q * estep * 4, 0));
-                    t.x *= w;
-                    t.y *= w;
-                }
-                v[i * R0 + j] = cf{t.x, t.y};
-            }
-        lds_fft_core<LOG2A, W>(v, lds_all, fr, tau, tw);
-        // B[k3 = tau + T q] * W_N^(m k3),  W_N^(m k3) = W_N^(m tau) * W_N^(m T q)
-        const __amdgpu_buffer_rsrc_t ro = frame_rsrc(scratch + f * nfft, (unsigned)(nfft * 8));
-        const float2 bw = t1T[e0];
-        const cf base = cf{bw.x, bw.y};
+        f = it / tiles;
+        m = (int)(it - f * tiles) * W + fr;
+    };
+    // B[k3 = tau + T q] * W_N^(m k3),  W_N^(m k3) = W_N^(m tau) * W_N^(m T q) = t1T[tau][m] * t2[m][q]
+    auto factors = [&](int m, cf (&bw)[16]) {
+        const float2 b0 = t1T[tau * M + m];
+        const cf base = cf{b0.x, b0.y};
         const float4* __restrict__ row = reinterpret_cast<const float4*>(t2 + (size_t)m * 16);
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
             const float4 w = row[q2];
-            const cf z0 = cmul(v[rev16(2 * q2)], cmul(base, cf{w.x, w.y}));
-            const cf z1 = cmul(v[rev16(2 * q2 + 1)], cmul(base, cf{w.z, w.w}));
-            const v2f s0 = {z0.x, z0.y}, s1 = {z1.x, z1.y};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, s0), ro, e0 * 8, (2 * q2) * estep * 8, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, s1), ro, e0 * 8, (2 * q2 + 1) * estep * 8, 0);
+            bw[2 * q2] = cmul(base, cf{w.x, w.y});
+            bw[2 * q2 + 1] = cmul(base, cf{w.z, w.w});
+        }
+    };
+    // the 16 loads of one tile (raw samples).  Buffer addressing: wave-uniform descriptor on the frame (zero-sized
+    // when there is no such item: the loads return zeros without touching memory), one 32-bit lane offset,
+    // uniform row steps
+    auto issue = [&](size_t g, v2f (&x)[16]) {
+        size_t f = 0;
+        int m = 0;
+        const bool live = g < items;
+        if (live) locate(g, f, m);
+        const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + f * frame_stride, live ? (unsigned)(nfft * 8) : 0u);
+        const int e0 = tau * M + m;          // element (n3 = tau, m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+#ifdef T2X_NOLOAD
+            x[q] = v2f{(float)(e0 + q), 1.0f};
+#else
+            x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, 2));
+#endif
+        }
+    };
+    auto store = [&](size_t f, int m, const cf (&v)[16], const cf (&bw)[16]) {
+        const __amdgpu_buffer_rsrc_t ro = frame_rsrc(scratch + f * nfft, (unsigned)(nfft * 8));
+        // k3 = tau + T q: lane part of the scratch index from (tau, m), uniform part from T q (both layouts are
+        // additive in that split because T q is a multiple of 16 or, for T = 8, tau + 8 stays inside one square)
+        const int so = scratch_index(tau, m, M);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const cf z = cmul(v[rev16(q)], bw[q]);
+            const v2f sv = {z.x, z.y};
+            const int u = scratch_index(T * q, 0, M);
+#ifdef T2X_NOSTORE
+            asm volatile("" :: "v"(sv.x), "v"(sv.y), "s"(u), "v"(so));
+#else
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, u * 8, T2_ST_AUX);
+#endif
+        }
+    };
+
+    if (FIXED) {
+        size_t f;
+        int m;
+        locate(blockIdx.x, f, m);            // m is the same for every item of this workgroup
+        float wreg[16];
+        if (HAS_WINDOW) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) wreg[q] = window[(size_t)(tau + T * q) * M + m];
+        }
+        cf bw[16];
+        factors(m, bw);
+        v2f xa[16], xb[16];
+        issue(blockIdx.x, xa);
+        for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
+            issue(g + gridDim.x, xb);
+            cf v[16];
+#pragma unroll
+            for (int i = 0; i < C0; ++i)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int q = i + C0 * j;
+                    v[i * R0 + j] = HAS_WINDOW ? cf{xa[q].x * wreg[q], xa[q].y * wreg[q]} : cf{xa[q].x, xa[q].y};
+                }
+            lds_fft_core<LOG2A, W>(v, lds_all, fr, tau, tw);
+            store(g / tiles, m, v, bw);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xa[q] = xb[q];
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t rw = frame_rsrc(window, HAS_WINDOW ? (unsigned)(nfft * 4) : 0u);
+        for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
+            size_t f;
+            int m;
+            locate(g, f, m);
+            v2f x[16];
+            issue(g, x);
+            const int e0 = tau * M + m;
+            cf v[16];
+#pragma unroll
+            for (int i = 0; i < C0; ++i)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int q = i + C0 * j;
+                    v2f t = x[q];
+                    if (HAS_WINDOW) {
+                        const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, e0 * 4, q * estep * 4, 0));
+                        t.x *= w;
+                        t.y *= w;
+                    }
+                    v[i * R0 + j] = cf{t.x, t.y};
+                }
+            lds_fft_core<LOG2A, W>(v, lds_all, fr, tau, tw);
+            cf bw[16];
+            factors(m, bw);
+            store(f, m, v, bw);
         }
     }
 }
@@ -124,14 +213,17 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS, (LdsCfg<LOG2M>::T * ROWS >
     for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
         const size_t f = it / tiles;
         const int k3_0 = (int)(it - f * tiles) * ROWS;
-        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)k3_0 * M, (unsigned)(ROWS * M * 8));
-        const int e0 = fr * M + tau;
+        // rows k3_0 .. k3_0+ROWS-1: the descriptor covers the 16-row band they lie in (for ROWS = 8 the tile is
+        // half of it); element (k3_0 + fr, m = tau + T c): lane part from (k3 & 15, tau), uniform part from T c
+        const int band = k3_0 & ~15;
+        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)band * M, (unsigned)(16 * M * 8));
+        const int e0 = scratch_index((k3_0 & 15) + fr, tau, M);
         cf v[16];
 #pragma unroll
         for (int i = 0; i < C0; ++i)
 #pragma unroll
             for (int j = 0; j < R0; ++j) {
-                const v2f t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, (i + C0 * j) * T * 8, 0));
+                const v2f t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, 0));
                 v[i * R0 + j] = cf{t.x, t.y};
             }
         lds_fft_core<LOG2M, 1>(v, lds, 0, tau, tw);
@@ -189,24 +281,38 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
     using C = LdsCfg<LOG2A>;
     constexpr int W = COL_TILE_W(LOG2A);
     const size_t lds_bytes = (size_t)(C::SLOT) * W * sizeof(float2);
-    const size_t items = nf * (size_t)(M / W);
+    const unsigned tiles = (unsigned)(M / W);
+    const size_t items = nf * (size_t)tiles;
     if (W == 8) grid_cap = (unsigned)a.num_cus * 2;
+    // The software-pipelined (FIXED) instances hold two tiles and their per-position factors in registers
+    // (<= 168 VGPRs): 3 workgroups per CU are resident, and a persistent grid must not exceed what is resident.
+    constexpr bool CAN_FIX = C::T * W <= 256 && W >= 16;
+    if (CAN_FIX && grid_cap > (unsigned)a.num_cus * 3) grid_cap = (unsigned)a.num_cus * 3;
     unsigned grid = (unsigned)(items < grid_cap ? items : grid_cap);
     if (W == 8 && grid >= 16) grid &= ~15u;
+    bool fixed = false;
+    if (CAN_FIX && grid >= tiles) {          // items is a multiple of tiles, so a rounded-down grid still divides evenly
+        grid -= grid % tiles;
+        fixed = true;
+    }
     const float2* twA = static_cast<const float2*>(a.d_twiddle_2p);
     const float2* t1T = twA + 2048 + 2048;
     const float2* t2 = t1T + (size_t)(C::T) * M;
     float2* scratch = static_cast<float2*>(a.d_scratch);
-#define SDRK_COL(WIN)                                                                                            \
+#define SDRK_COL(WIN, FIX)                                                                                       \
     do {                                                                                                         \
-        auto kern = col_pass_kernel<LOG2A, WIN, W>;                                                              \
+        auto kern = col_pass_kernel<LOG2A, WIN, W, FIX>;                                                         \
         static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                     \
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
         if (e0 != hipSuccess) return e0;                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * W), lds_bytes, a.stream, src, a.frame_stride, scratch, nf, \
                            M, a.d_window, twA, t1T, t2);                                                            \
     } while (0)
-    if (a.d_window) SDRK_COL(true); else SDRK_COL(false);
+    if (CAN_FIX && fixed) {
+        if (a.d_window) SDRK_COL(true, CAN_FIX); else SDRK_COL(false, CAN_FIX);
+    } else {
+        if (a.d_window) SDRK_COL(true, false); else SDRK_COL(false, false);
+    }
 #undef SDRK_COL
     return hipGetLastError();
 }
@@ -252,8 +358,26 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
         if (per_cu < 1) per_cu = 1;
         return (unsigned)(a.num_cus * per_cu);
     };
-    for (size_t f0 = 0; f0 < a.n_frames; f0 += a.scratch_frames) {
-        const size_t nf = (a.n_frames - f0 < a.scratch_frames) ? a.n_frames - f0 : a.scratch_frames;
+    // Frames per chunk: the scratch capacity, rounded down to a whole number of grid passes of BOTH kernels
+    // (col: 3 workgroups per CU when software-pipelined, else cap(A); row: cap(M)) so that no persistent
+    // workgroup gets one work item more than its neighbours (N = 65536: 256 frames = 5.33 col items per
+    // workgroup became 192 = exactly 4 col and 3 row items).
+    size_t chunk = a.scratch_frames;
+    {
+        auto gcd = [](size_t x, size_t y) { while (y) { size_t t = x % y; x = y; y = t; } return x; };
+        const int Wc = COL_TILE_W(la <= 11 ? la : 11), Rr = ROW_TILE_R(lm <= 11 ? lm : 11);
+        const bool pipelined = (A / 16) * Wc <= 256 && Wc >= 16;
+        size_t col_grid = Wc == 8 ? (size_t)a.num_cus * 2 : (pipelined ? (size_t)a.num_cus * 3 : cap(A < 1024 ? A : 1024));
+        if (pipelined && col_grid > cap(A)) col_grid = cap(A);
+        const size_t row_grid = cap(M < 1024 ? M : 1024);
+        size_t cw = col_grid / (size_t)(M / Wc), rw = row_grid / (size_t)(A / Rr);
+        if (cw < 1) cw = 1;
+        if (rw < 1) rw = 1;
+        const size_t l = cw / gcd(cw, rw) * rw;
+        if (chunk >= l) chunk -= chunk % l;
+    }
+    for (size_t f0 = 0; f0 < a.n_frames; f0 += chunk) {
+        const size_t nf = (a.n_frames - f0 < chunk) ? a.n_frames - f0 : chunk;
         const float2* src = iq + f0 * a.frame_stride;
         void* dst = static_cast<char*>(a.d_out) + f0 * (size_t)a.nfft * out_elem;
         hipError_t e;

@@ -608,8 +608,11 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
         PLAN_TRY(hipMalloc((void**)&p->d_twiddle, sizeof(float2) * nfft));
         PLAN_TRY(hipMemcpy(p->d_twiddle, t.data(), sizeof(float2) * nfft, hipMemcpyHostToDevice));
     } else {
-        // scratch between the two passes: up to 128 MiB of complex64 frames (stays in the 256 MiB Infinity Cache)
-        size_t scratch_mb = 128;
+        // scratch between the two passes: up to 192 MiB of complex64 frames.  It has to stay in the 256 MiB
+        // Infinity Cache between the col pass that writes it and the row pass that reads it, and per-launch
+        // costs favour few large chunks: measured on config 3 (N = 65536), 96 / 192 / 288 / 384 / 576 MiB give
+        // 6.15 / 5.61 / 5.99 / 6.95 / 7.23 ms (the step past 256 MiB is the cache being outrun).
+        size_t scratch_mb = 192;
         if (const char* env = getenv("SDRK_SCRATCH_MB")) {  // tuning knob (developer use)
             long v = atol(env);
             if (v >= 1 && v <= 65536) scratch_mb = (size_t)v;

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of one round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r02
+# kernel-trace + stats of the default bench, FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, as the
+# MI355X guide prescribes) of the bench and of BASELINE configs 3 and 5.  Outputs under gpurun_out/prof_<tag>/;
+# tools/summarise_profiles.py turns them into the files committed under profiles/<tag>/.
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+run() {  # name, rocprof args..., -- program args
+    local name=$1; shift
+    echo "== $name" >&2
+    rocprofv3 "$@" > "$OUT/$name.stdout" 2> "$OUT/$name.stderr" || echo "rocprofv3 $name failed rc=$?" >&2
+}
+BENCH_SHORT="--steps 3 --warmup 1 --cpu-seconds 0 --parity-frames 0 --no-secondary"
+run bench_trace --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 "$ROOT/bench.py" --no-secondary --cpu-seconds 0
+run bench_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_fetch" -- python3 "$ROOT/bench.py" $BENCH_SHORT
+run bench_write --pmc WRITE_SIZE --output-format csv -d "$OUT/bench_write" -- python3 "$ROOT/bench.py" $BENCH_SHORT
+for cfg in "cfg3 65536 18749 32768 hann" "cfg5 1048576 256 1048576 hann"; do
+    set -- $cfg
+    run $1_trace --kernel-trace --stats --output-format csv -d "$OUT/$1_trace" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5
+    run $1_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/$1_fetch" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5
+    run $1_write --pmc WRITE_SIZE --output-format csv -d "$OUT/$1_write" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5
+done
+python3 "$ROOT/tools/summarise_profiles.py" "$OUT" > "$OUT/summary.json" 2> "$OUT/summary.err"
+cat "$OUT/summary.json"

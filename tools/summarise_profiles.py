@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output directories written by tools/profile_round.sh into one JSON summary:
+per kernel the call count and average duration (kernel-trace --stats) and the mean FETCH_SIZE / WRITE_SIZE
+per dispatch with the gfx950 correction applied (read bytes = 2 x FETCH_SIZE KB x 1024: the counter tallies
+each 128-byte request as 64 bytes; WRITE_SIZE KB x 1024 is exact — MI355X_MICROARCH.md, HBM section).
+Infinity-Cache hits are included in both counters (they count L2 <-> fabric requests)."""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"sdrk::(\w+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+def stats(dirname):
+    out = {}
+    for f in glob.glob(os.path.join(dirname, "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            out[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_us": round(float(row["AverageNs"]) / 1e3, 3),
+                                       "min_us": round(float(row["MinNs"]) / 1e3, 3), "max_us": round(float(row["MaxNs"]) / 1e3, 3),
+                                       "total_ms": round(float(row["TotalDurationNs"]) / 1e6, 4)}
+    return out
+
+
+def pmc(dirname, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter:
+                acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    return {k: {"dispatches": len(v), "mean_KB": sum(v) / len(v), "sum_KB": sum(v)} for k, v in acc.items()}
+
+
+def main(root):
+    res = {}
+    for tag in ("bench", "cfg3", "cfg5"):
+        st, fe, wr = stats(f"{root}/{tag}_trace"), pmc(f"{root}/{tag}_fetch", "FETCH_SIZE"), pmc(f"{root}/{tag}_write", "WRITE_SIZE")
+        kernels = {}
+        for k in sorted(set(st) | set(fe) | set(wr)):
+            rec = dict(st.get(k, {}))
+            if k in fe:
+                rec["FETCH_SIZE_KB_mean"] = round(fe[k]["mean_KB"], 3)
+                rec["read_bytes_per_dispatch"] = round(2 * fe[k]["mean_KB"] * 1024)
+                rec["pmc_dispatches"] = fe[k]["dispatches"]
+            if k in wr:
+                rec["WRITE_SIZE_KB_mean"] = round(wr[k]["mean_KB"], 3)
+                rec["write_bytes_per_dispatch"] = round(wr[k]["mean_KB"] * 1024)
+            kernels[k] = rec
+        res[tag] = kernels
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r02")
