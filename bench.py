@@ -314,6 +314,66 @@ def numpy_boundary(lib, _ffi, pkg, synth, dev):
     return out
 
 
+def feature_reductions(lib, _ffi, SpectrumPlan, features, dev, n_frames=1 << 18):
+    """classifier.py:163-212 next to the rows, device resident, N = 4096 Hann: (a) the fused
+    form — reductions as the epilogue of the transform, rows never written; (b) the transform followed by the
+    stand-alone single-read reduction kernel over its rows."""
+    n, max_peaks = NFFT, 64
+    rank, gamma = features.percentile_rank(n, 20.0), float(features.percentile_gamma(n, 20.0))
+    bufs = {}
+
+    def alloc(name, nbytes):
+        bufs[name] = ctypes.c_void_p()
+        _ffi.check(lib.sdrk_dev_alloc(dev, nbytes, ctypes.byref(bufs[name])))
+
+    try:
+        alloc("iq", n_frames * n * 8); alloc("rows", n_frames * n * 4); alloc("stats", n_frames * 16 * 8)
+        alloc("thr", n_frames * 8); alloc("idx", n_frames * max_peaks * 4); alloc("cnt", n_frames * 4)
+        _ffi.check(lib.sdrk_synth_fill(dev, 4321, 0, n_frames, n, bufs["iq"], None))
+        out = {"nfft": n, "frames": n_frames, "window": "hann", "max_peaks": max_peaks}
+        with SpectrumPlan(n, window="hann", device=dev) as plan:
+            def fused(rows_ptr):
+                _ffi.check(lib.sdrk_frame_features_device(plan.handle, bufs["iq"], n_frames, n, rows_ptr, rank,
+                                                          ctypes.c_float(gamma), max(3, n // 300), max_peaks, bufs["stats"],
+                                                          bufs["thr"], bufs["idx"], bufs["cnt"], None))
+                plan.sync()
+
+            def timed(fn):
+                fn()
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+                return _median(ts)
+
+            t = timed(lambda: fused(None))
+            out["fused_rows_not_written"] = {"ms": round(t * 1e3, 3), "rows_per_s": round(n_frames / t),
+                                             "Msamples_per_s": round(n_frames * n / t / 1e6, 1),
+                                             "algorithmic_bytes": 8 * n_frames * n, "algorithmic_formula": "8*frames*N (IQ read only)",
+                                             "GBps": round(8 * n_frames * n / t / 1e9, 1),
+                                             "frac": round(8 * n_frames * n / t / 1e9 / HBM_PEAK_GBPS, 4)}
+            t = timed(lambda: fused(bufs["rows"]))
+            out["fused_rows_also_written"] = {"ms": round(t * 1e3, 3), "rows_per_s": round(n_frames / t),
+                                              "GBps": round(12 * n_frames * n / t / 1e9, 1)}
+
+            def separate():
+                plan.exec_device(bufs["iq"].value, n_frames, bufs["rows"].value)
+                plan.sync()
+                _ffi.check(lib.sdrk_row_features(dev, bufs["rows"], 1, n_frames, n, rank, ctypes.c_float(gamma),
+                                                 max(3, n // 300), max_peaks, host_stats.ctypes.data_as(ctypes.c_void_p),
+                                                 None, None, None))
+
+            import numpy as np
+            host_stats = np.empty((n_frames, 16), dtype=np.float64)
+            t = timed(separate)
+            out["transform_then_row_features_host_stats"] = {"ms": round(t * 1e3, 3), "rows_per_s": round(n_frames / t)}
+        return out
+    finally:
+        for b in bufs.values():
+            lib.sdrk_dev_free(dev, b)
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -443,6 +503,8 @@ def main():
             r["realtime_factor_at_61.44_Msps"] = round((256 * (1 << 20) / 61.44e6) / (r["ms"] * 1e-3), 1)
             secondary["config5_one_channel"] = r
             secondary["numpy_boundary"] = numpy_boundary(lib, _ffi, pkg, synth, dev)
+            from sdr_iq_visualizer_amd import features
+            secondary["row_features"] = feature_reductions(lib, _ffi, SpectrumPlan, features, dev)
         except Exception as e:
             secondary["error"] = f"{type(e).__name__}: {e}"
 

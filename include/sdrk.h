@@ -180,21 +180,49 @@ int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_fr
  * float32, on the host (rows_on_device = 0) or already on `device` (non-zero, e.g.
  * the output of sdrk_exec_device).
  *
- * sdrk_row_stats: out[r*16 + i] (double), i =
+ * stats: out[r*16 + i] (double), i =
  *   0 max | 1 sorted[rank] | 2 sorted[rank+1] (order statistics of the row, for the
  *   percentile noise floor, classifier.py:179-181) | 3 mean | 4 mean (x-mean)^2 |
  *   5 mean (x-mean)^4 (:191-198) | 6 mean ln p | 7 mean p, p = max(10^(x/10), 1e-15)
  *   (:183-189) | 8,9 first,last index with x >= max-3 | 10,11 ... max-10 | 12,13 ...
  *   max-20 (:163-170) | 14 argmax | 15 nfft.
- * sdrk_row_peaks: strict local maxima above thresholds[r], accepted left to right
- *   when >= min_distance bins after the previous accepted one (:200-212).
+ * thr: the adaptive peak threshold of classifier.py:55, max(noise_floor + 5,
+ *   max - 0.9*snr + 5), with the percentile interpolated as numpy.percentile does on a
+ *   float32 row: noise_floor = sorted[rank] + (sorted[rank+1]-sorted[rank])*gamma
+ *   (`rank`, `gamma` = floor and fraction of float32(nfft-1)*float32(q/100)).
+ * peaks: strict local maxima above the threshold, accepted left to right when
+ *   >= min_distance bins after the previous accepted one (:200-212).
  *   out_idx: n_rows*max_peaks int32 (first max_peaks peaks of each row),
- *   out_count: n_rows int32 (may exceed max_peaks: the total found). */
+ *   out_count: n_rows int32 (may exceed max_peaks: the total found).
+ *
+ * sdrk_row_features: everything in ONE launch that reads each row from HBM once (rows up
+ *   to 32768 bins are staged in LDS; longer rows are scanned in place); out_thr, out_idx
+ *   and out_count may be NULL (then only the stats are produced).
+ * sdrk_row_stats / sdrk_row_peaks: the two halves separately (sdrk_row_peaks takes the
+ *   thresholds from the caller). */
+int sdrk_row_features(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft,
+                      int rank, float gamma, int min_distance, int max_peaks, double* out_stats,
+                      double* out_thr, int32_t* out_idx, int32_t* out_count);
 int sdrk_row_stats(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft,
                    int rank, double* out);
 int sdrk_row_peaks(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft,
                    const double* thresholds, int min_distance, int max_peaks, int32_t* out_idx,
                    int32_t* out_count);
+
+/* IQ frames -> those measurements, the rows staying on the device (streamer.py:119,121
+ * followed by classifier.py:163-212).  For nfft = 4096 the reductions run as the epilogue
+ * of the transform kernel itself: the row exists only in LDS unless the caller passes a
+ * buffer for it.  _device: every pointer is device memory, asynchronous on `stream` (or
+ * the plan's stream); d_out_db, d_thr, d_idx/d_count may be NULL.  _host: host pointers,
+ * blocking; out_db (the rows) may be NULL. */
+int sdrk_frame_features_device(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames,
+                               size_t frame_stride, float* d_out_db, int rank, float gamma,
+                               int min_distance, int max_peaks, double* d_stats, double* d_thr,
+                               int32_t* d_idx, int32_t* d_count, void* stream);
+int sdrk_frame_features_host(sdrk_plan* plan, const void* iq_c64, size_t n_frames,
+                             size_t frame_stride, int rank, float gamma, int min_distance,
+                             int max_peaks, double* out_stats, double* out_thr, int32_t* out_idx,
+                             int32_t* out_count, float* out_db);
 
 /* ---- waterfall ring -------------------------------------------------------
  * Replaces deque(maxlen=100) / append / np.array(deque) at

@@ -76,6 +76,12 @@ SYMBOLS = [
     ("sdrk_host_link_probe", c_int, [c_int, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     ("sdrk_host_threads", c_int, []),
     ("sdrk_synth_fill", c_int, [c_int, c_uint32, c_uint64, c_size_t, c_int, c_void_p, c_void_p]),
+    ("sdrk_row_features", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_int, c_float, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("sdrk_frame_features_device", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, c_float, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("sdrk_frame_features_host", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_float, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("sdrk_row_stats", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p]),
     ("sdrk_row_peaks", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("sdrk_waterfall_create", c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),

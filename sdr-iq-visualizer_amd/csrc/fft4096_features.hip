@@ -1,0 +1,103 @@
+// fft4096_features.hip — the N = 4096 transform with the classifier's per-row measurements as its
+// epilogue: window * x -> FFT -> fftshift -> 20*log10(|X| + eps)  (app/sdr/streamer.py:119,121), then,
+// while the row is still on chip, the reductions of app/processing/classifier.py:163-212
+// (row_features_core.h).  The row itself is written to HBM only if the caller wants it: a consumer
+// that needs the ~20 scalars and the peak list per frame costs 8 B/sample of HBM traffic (the IQ read)
+// instead of 8 + 4 (row written) + 4 (row read back by a separate reduction kernel).
+//
+// Same decomposition, LDS layouts and software pipeline as fft4096.hip (kept as a separate kernel so that
+// the flagship's register allocation is untouched); after the last pass the 16 KiB row replaces the
+// exchange buffer in LDS, followed by the reduction scratch.
+#include "fft4096_core.h"
+#include "row_features_core.h"
+
+namespace sdrk {
+
+template <bool HAS_WINDOW>
+__global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_features_kernel(
+    const float2* __restrict__ iq, size_t frame_stride, float* __restrict__ out_db, size_t n_frames,
+    const float* __restrict__ window, const float2* __restrict__ tw4096, float eps, int shift, RowFeatParams prm,
+    double* __restrict__ stats, double* __restrict__ thr, int* __restrict__ idx, int* __restrict__ cnt) {
+    __shared__ float2 lds[F4K_XCH_ELEMS + F4K_TW_ELEMS + (HAS_WINDOW ? F4K_N / 2 : 0)];
+    static_assert(F4K_XCH_ELEMS * sizeof(float2) >= F4K_N * sizeof(float) + sizeof(RowFeatShared) + 16,
+                  "row + reduction scratch must fit the exchange buffer");
+    float2* __restrict__ tw256 = lds + F4K_XCH_ELEMS;
+    float2* __restrict__ tw4k = tw256 + 256;
+    float* __restrict__ lds_win = reinterpret_cast<float*>(tw4k + 256);
+    float* __restrict__ row = reinterpret_cast<float*>(lds);                                  // 4096 float32
+    RowFeatShared& sh = *reinterpret_cast<RowFeatShared*>(reinterpret_cast<char*>(lds) + F4K_N * sizeof(float));
+
+    const int tid = threadIdx.x;
+    F4kAddr A = f4k_addr(tid);
+    f4k_init_tables(tw256, tw4k, tw4096, tid, A);
+    if (HAS_WINDOW) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lds_win[tid + 256 * j] = window[tid + 256 * j];
+    }
+    __syncthreads();
+
+    const int xor_k2 = shift ? 8 : 0;
+    const int voff_in = tid * 8;
+    const size_t first = blockIdx.x, step = gridDim.x;
+    v2u nxt[16];
+    {
+        __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + first * frame_stride, F4K_N * 8);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, 2);
+    }
+    for (size_t f = first; f < n_frames; f += step) {
+        cf v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v2f t = __builtin_bit_cast(v2f, nxt[j]);
+            v[j] = cf{t.x, t.y};
+        }
+        {
+            size_t fn = f + step;
+            if (fn >= n_frames) fn = f;  // harmless re-read on the last trip
+            __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + fn * frame_stride, F4K_N * 8);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, 2);
+        }
+        if (HAS_WINDOW) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = v[j] * lds_win[tid + 256 * j];
+        }
+        f4k_transform<false>(v, lds, tw256, tw4k, A, tid);
+        __syncthreads();   // every thread is through its last exchange read: the buffer becomes the row
+        // bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor)
+        __amdgpu_buffer_rsrc_t w = frame_rsrc(out_db ? out_db + f * (size_t)F4K_N : nullptr, out_db ? F4K_N * 4 : 0);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const cf z = v[rev16(k2)];
+            const float db = logpsd_db(z.x, z.y, eps);
+            row[tid + 256 * (k2 ^ xor_k2)] = db;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, db), w, tid * 4, (k2 ^ xor_k2) * 1024, 2);
+        }
+        __syncthreads();
+        row_features_wg(row, F4K_N, prm, sh, stats + f * 16, thr ? thr + f : nullptr,
+                        idx ? idx + f * (size_t)prm.max_peaks : nullptr, cnt ? cnt + f : nullptr);
+        __syncthreads();   // row and scratch are overwritten by the next frame's first exchange
+    }
+}
+
+hipError_t launch_fft4096_features(const LaunchArgs& a, int rank, float gamma, int min_distance, int max_peaks,
+                                   double* d_stats, double* d_thr, int* d_idx, int* d_cnt) {
+    if (a.n_frames == 0) return hipSuccess;
+    if (a.nfft != F4K_N) return hipErrorInvalidValue;
+    RowFeatParams prm{rank, gamma, min_distance, max_peaks};
+    const size_t max_blocks = (size_t)a.num_cus * F4K_WAVES;
+    const unsigned grid = (unsigned)(a.n_frames < max_blocks ? a.n_frames : max_blocks);
+    const float2* iq = static_cast<const float2*>(a.d_iq);
+    const float2* tw = static_cast<const float2*>(a.d_twiddle);
+    float* out = static_cast<float*>(a.d_out);
+    if (a.d_window)
+        hipLaunchKernelGGL((fft4096_features_kernel<true>), dim3(grid), dim3(F4K_THREADS), 0, a.stream, iq, a.frame_stride,
+                           out, a.n_frames, a.d_window, tw, a.eps, a.shift, prm, d_stats, d_thr, d_idx, d_cnt);
+    else
+        hipLaunchKernelGGL((fft4096_features_kernel<false>), dim3(grid), dim3(F4K_THREADS), 0, a.stream, iq, a.frame_stride,
+                           out, a.n_frames, a.d_window, tw, a.eps, a.shift, prm, d_stats, d_thr, d_idx, d_cnt);
+    return hipGetLastError();
+}
+
+}  // namespace sdrk

@@ -94,7 +94,13 @@ hipError_t launch_blu_mul(const void* d_A, const void* d_B, size_t n_frames, int
                           hipStream_t s);
 hipError_t launch_blu_post(const void* d_Y, const void* d_chirp, size_t n_frames, int N, int M, float eps, int shift,
                            int epilogue, void* d_out, int num_cus, hipStream_t s);
-hipError_t launch_row_stats(const float* d_rows, size_t n_rows, int nfft, int rank, double* d_out, hipStream_t s);
+// per-row measurements (row_features.hip): stats[16], adaptive threshold, peak list; d_thr/d_idx/d_cnt may be null
+hipError_t launch_row_features(const float* d_rows, size_t n_rows, int nfft, int rank, float gamma, int min_distance,
+                               int max_peaks, double* d_stats, double* d_thr, int* d_idx, int* d_cnt, int num_cus,
+                               hipStream_t s);
+// the N = 4096 transform with those measurements as its epilogue (fft4096_features.hip); a.d_out may be null
+hipError_t launch_fft4096_features(const LaunchArgs& a, int rank, float gamma, int min_distance, int max_peaks,
+                                   double* d_stats, double* d_thr, int* d_idx, int* d_cnt);
 hipError_t launch_row_peaks(const float* d_rows, size_t n_rows, int nfft, const double* d_thr, int min_distance,
                             int max_peaks, int* d_idx, int* d_count, hipStream_t s);
 hipError_t launch_decimate_rows(const float* d_ring, int nfft, int maxlen, int start_slot, int n_rows, int factor,

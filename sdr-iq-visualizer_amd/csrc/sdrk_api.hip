@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -99,6 +100,8 @@ struct sdrk_plan {
     size_t in_cap = 0;
     void* d_out = nullptr;
     size_t out_cap = 0;
+    void* d_feat = nullptr;          // per-row feature results of sdrk_frame_features_host (only grows)
+    size_t feat_cap = 0;
     float2* d_tw_2p = nullptr;       // two-pass tiled plans (fft_tiled2.hip)
     bool tiled2 = false;
     // sdrk_exec_host pipeline: HOST_SLOTS chunks in flight, each with pinned host and device staging
@@ -138,6 +141,8 @@ struct sdrk_waterfall {
     size_t head = 0;          // slot the next row is written to
     size_t count = 0;         // valid rows (<= maxlen)
     hipStream_t stream = nullptr;
+    void* d_dec = nullptr;    // decimated read-out staging (only grows)
+    size_t dec_cap = 0;
 };
 
 namespace {
@@ -688,6 +693,7 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->h_fused_err) (void)hipHostFree(p->h_fused_err);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
+    if (p->d_feat) (void)hipFree(p->d_feat);
     if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
     if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
     for (auto& sl : p->slot) {
@@ -915,32 +921,91 @@ int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_fr
 /* ---- per-row reductions ---------------------------------------------------- */
 
 namespace {
-struct DevBuf {  // scoped device allocation
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+
+// Device scratch of the plan-less row entry points: one buffer per device, only ever grown, used under the
+// device's lock (calls on one device serialise; different devices run concurrently).
+struct RowScratch {
+    std::mutex lock;
+    void* buf = nullptr;
+    size_t cap = 0;
 };
+RowScratch g_row_scratch[64];
+
+struct RowScratchGuard {
+    RowScratch* rs;
+    explicit RowScratchGuard(int device) : rs(&g_row_scratch[device & 63]) { rs->lock.lock(); }
+    ~RowScratchGuard() { rs->lock.unlock(); }
+    int reserve(int device, size_t bytes) { return grow(device, &rs->buf, &rs->cap, bytes); }
+};
+
+constexpr size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// layout of the packed per-row results in a scratch buffer
+struct FeatLayout {
+    size_t rows_off, stats_off, thr_off, idx_off, cnt_off, total;
+    FeatLayout(size_t n_rows, int nfft, int max_peaks, bool stage_rows, bool peaks) {
+        size_t o = 0;
+        rows_off = o;  o += stage_rows ? align256(n_rows * (size_t)nfft * sizeof(float)) : 0;
+        stats_off = o; o += align256(n_rows * 16 * sizeof(double));
+        thr_off = o;   o += align256(n_rows * sizeof(double));
+        idx_off = o;   o += peaks ? align256(n_rows * (size_t)max_peaks * sizeof(int)) : 0;
+        cnt_off = o;   o += peaks ? align256(n_rows * sizeof(int)) : 0;
+        total = o;
+    }
+};
+
+int device_cus(int device, int* cus) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    *cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return SDRK_OK;
+}
+
 }  // namespace
 
-int sdrk_row_stats(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
-                   double* out) {
+int sdrk_row_features(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
+                      float gamma, int min_distance, int max_peaks, double* out_stats, double* out_thr,
+                      int32_t* out_idx, int32_t* out_count) {
     if (n_rows == 0) return SDRK_OK;
-    if (!rows || !out) return fail(SDRK_ERR_INVALID, "rows or out is NULL");
+    if (!rows || !out_stats) return fail(SDRK_ERR_INVALID, "rows or out_stats is NULL");
     if (nfft < 1) return fail(SDRK_ERR_INVALID, "nfft must be >= 1");
+    const bool peaks = out_idx != nullptr || out_count != nullptr;
+    if (peaks && (!out_idx || !out_count || max_peaks < 1 || min_distance < 1))
+        return fail(SDRK_ERR_INVALID, "peaks need out_idx, out_count and max_peaks, min_distance >= 1");
     int st = check_device(device);
     if (st != SDRK_OK) return st;
     HIP_TRY(hipSetDevice(device));
-    DevBuf drows, dout;
+    int cus = 256;
+    st = device_cus(device, &cus);
+    if (st != SDRK_OK) return st;
+    RowScratchGuard g(device);
+    const FeatLayout L(n_rows, nfft, max_peaks, !rows_on_device, peaks);
+    st = g.reserve(device, L.total);
+    if (st != SDRK_OK) return st;
+    char* base = static_cast<char*>(g.rs->buf);
     const float* d_rows = rows;
     if (!rows_on_device) {
-        HIP_TRY(hipMalloc(&drows.p, n_rows * (size_t)nfft * sizeof(float)));
-        HIP_TRY(hipMemcpy(drows.p, rows, n_rows * (size_t)nfft * sizeof(float), hipMemcpyHostToDevice));
-        d_rows = static_cast<const float*>(drows.p);
+        HIP_TRY(hipMemcpy(base + L.rows_off, rows, n_rows * (size_t)nfft * sizeof(float), hipMemcpyHostToDevice));
+        d_rows = reinterpret_cast<const float*>(base + L.rows_off);
     }
-    HIP_TRY(hipMalloc(&dout.p, n_rows * 16 * sizeof(double)));
-    hipError_t e = sdrk::launch_row_stats(d_rows, n_rows, nfft, rank, static_cast<double*>(dout.p), nullptr);
-    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "row_stats launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpy(out, dout.p, n_rows * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    hipError_t e = sdrk::launch_row_features(d_rows, n_rows, nfft, rank, gamma, min_distance, max_peaks,
+                                             reinterpret_cast<double*>(base + L.stats_off),
+                                             reinterpret_cast<double*>(base + L.thr_off),
+                                             peaks ? reinterpret_cast<int*>(base + L.idx_off) : nullptr,
+                                             peaks ? reinterpret_cast<int*>(base + L.cnt_off) : nullptr, cus, nullptr);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "row_features launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(out_stats, base + L.stats_off, n_rows * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_thr) HIP_TRY(hipMemcpy(out_thr, base + L.thr_off, n_rows * sizeof(double), hipMemcpyDeviceToHost));
+    if (peaks) {
+        HIP_TRY(hipMemcpy(out_idx, base + L.idx_off, n_rows * (size_t)max_peaks * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_count, base + L.cnt_off, n_rows * sizeof(int), hipMemcpyDeviceToHost));
+    }
     return SDRK_OK;
+}
+
+int sdrk_row_stats(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
+                   double* out) {
+    return sdrk_row_features(device, rows, rows_on_device, n_rows, nfft, rank, 0.0f, 1, 1, out, nullptr, nullptr, nullptr);
 }
 
 int sdrk_row_peaks(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft,
@@ -953,23 +1018,116 @@ int sdrk_row_peaks(int device, const float* rows, int rows_on_device, size_t n_r
     int st = check_device(device);
     if (st != SDRK_OK) return st;
     HIP_TRY(hipSetDevice(device));
-    DevBuf drows, dthr, didx, dcnt;
+    RowScratchGuard g(device);
+    const FeatLayout L(n_rows, nfft, max_peaks, !rows_on_device, true);
+    st = g.reserve(device, L.total);
+    if (st != SDRK_OK) return st;
+    char* base = static_cast<char*>(g.rs->buf);
     const float* d_rows = rows;
     if (!rows_on_device) {
-        HIP_TRY(hipMalloc(&drows.p, n_rows * (size_t)nfft * sizeof(float)));
-        HIP_TRY(hipMemcpy(drows.p, rows, n_rows * (size_t)nfft * sizeof(float), hipMemcpyHostToDevice));
-        d_rows = static_cast<const float*>(drows.p);
+        HIP_TRY(hipMemcpy(base + L.rows_off, rows, n_rows * (size_t)nfft * sizeof(float), hipMemcpyHostToDevice));
+        d_rows = reinterpret_cast<const float*>(base + L.rows_off);
     }
-    HIP_TRY(hipMalloc(&dthr.p, n_rows * sizeof(double)));
-    HIP_TRY(hipMemcpy(dthr.p, thresholds, n_rows * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&didx.p, n_rows * (size_t)max_peaks * sizeof(int)));
-    HIP_TRY(hipMalloc(&dcnt.p, n_rows * sizeof(int)));
-    hipError_t e = sdrk::launch_row_peaks(d_rows, n_rows, nfft, static_cast<const double*>(dthr.p), min_distance,
-                                          max_peaks, static_cast<int*>(didx.p), static_cast<int*>(dcnt.p), nullptr);
+    HIP_TRY(hipMemcpy(base + L.thr_off, thresholds, n_rows * sizeof(double), hipMemcpyHostToDevice));
+    hipError_t e = sdrk::launch_row_peaks(d_rows, n_rows, nfft, reinterpret_cast<const double*>(base + L.thr_off),
+                                          min_distance, max_peaks, reinterpret_cast<int*>(base + L.idx_off),
+                                          reinterpret_cast<int*>(base + L.cnt_off), nullptr);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "row_peaks launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpy(out_idx, didx.p, n_rows * (size_t)max_peaks * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_count, dcnt.p, n_rows * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_idx, base + L.idx_off, n_rows * (size_t)max_peaks * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_count, base + L.cnt_off, n_rows * sizeof(int), hipMemcpyDeviceToHost));
     return SDRK_OK;
+}
+
+int sdrk_frame_features_device(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride,
+                               float* d_out_db, int rank, float gamma, int min_distance, int max_peaks,
+                               double* d_stats, double* d_thr, int32_t* d_idx, int32_t* d_count, void* stream) {
+    if (!p) return fail(SDRK_ERR_INVALID, "plan is NULL");
+    if (n_frames == 0) return SDRK_OK;
+    if (!d_iq || !d_stats) return fail(SDRK_ERR_INVALID, "d_iq or d_stats is NULL");
+    const bool peaks = d_idx != nullptr || d_count != nullptr;
+    if (peaks && (!d_idx || !d_count || max_peaks < 1 || min_distance < 1))
+        return fail(SDRK_ERR_INVALID, "peaks need d_idx, d_count and max_peaks, min_distance >= 1");
+    if (frame_stride == 0 && n_frames > 1) return fail(SDRK_ERR_INVALID, "frame_stride must be >= 1");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    if (p->nfft == 4096) {
+        // fused: the rows never leave the chip unless d_out_db asks for them (fft4096_features.hip)
+        sdrk::LaunchArgs a;
+        a.d_iq = d_iq; a.frame_stride = frame_stride; a.d_out = d_out_db; a.n_frames = n_frames; a.nfft = 4096;
+        a.d_window = p->d_window; a.d_twiddle = p->d_twiddle; a.eps = p->eps; a.shift = p->shift;
+        a.stream = s; a.num_cus = p->num_cus;
+        hipError_t e = sdrk::launch_fft4096_features(a, rank, gamma, min_distance, max_peaks > 0 ? max_peaks : 1, d_stats,
+                                                     d_thr, peaks ? d_idx : nullptr, peaks ? d_count : nullptr);
+        if (e != hipSuccess) return fail(SDRK_ERR_HIP, "fused feature launch failed: %s", hipGetErrorString(e));
+        return SDRK_OK;
+    }
+    // other frame lengths: the transform writes its rows (to the caller's buffer, or to plan staging in
+    // chunks), then one single-read reduction launch per chunk
+    const size_t nfft = (size_t)p->nfft;
+    size_t per = n_frames;
+    float* rows = d_out_db;
+    if (!rows) {
+        per = ((size_t)256 << 20) / (nfft * sizeof(float));
+        if (per < 1) per = 1;
+        if (per > n_frames) per = n_frames;
+        int st = grow(p->device, &p->d_out, &p->out_cap, per * nfft * sizeof(float));
+        if (st != SDRK_OK) return st;
+        rows = static_cast<float*>(p->d_out);
+    }
+    for (size_t f0 = 0; f0 < n_frames; f0 += per) {
+        const size_t nf = n_frames - f0 < per ? n_frames - f0 : per;
+        float* dst = d_out_db ? d_out_db + f0 * nfft : rows;
+        int st = plan_launch(p, static_cast<const float2*>(d_iq) + f0 * frame_stride, nf, frame_stride, dst,
+                             sdrk::EPI_LOGPSD, s);
+        if (st != SDRK_OK) return st;
+        hipError_t e = sdrk::launch_row_features(dst, nf, p->nfft, rank, gamma, min_distance, max_peaks > 0 ? max_peaks : 1,
+                                                 d_stats + f0 * 16, d_thr ? d_thr + f0 : nullptr,
+                                                 peaks ? d_idx + f0 * (size_t)max_peaks : nullptr,
+                                                 peaks ? d_count + f0 : nullptr, p->num_cus, s);
+        if (e != hipSuccess) return fail(SDRK_ERR_HIP, "row_features launch failed: %s", hipGetErrorString(e));
+    }
+    return SDRK_OK;
+}
+
+int sdrk_frame_features_host(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride, int rank,
+                             float gamma, int min_distance, int max_peaks, double* out_stats, double* out_thr,
+                             int32_t* out_idx, int32_t* out_count, float* out_db) {
+    int st = check_exec_args(p, iq, n_frames, frame_stride, out_stats);
+    if (st != SDRK_OK || n_frames == 0) return st;
+    const bool peaks = out_idx != nullptr || out_count != nullptr;
+    if (peaks && (!out_idx || !out_count || max_peaks < 1 || min_distance < 1))
+        return fail(SDRK_ERR_INVALID, "peaks need out_idx, out_count and max_peaks, min_distance >= 1");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t nfft = (size_t)p->nfft;
+    const size_t in_bytes = ((n_frames - 1) * frame_stride + nfft) * sizeof(float2);
+    st = grow(p->device, &p->d_in, &p->in_cap, in_bytes);
+    if (st != SDRK_OK) return st;
+    // results (and the rows, when the caller wants them or the frame length has no fused kernel) in a second
+    // staging buffer that only grows
+    const bool need_rows = out_db != nullptr;
+    const FeatLayout L(n_frames, p->nfft, max_peaks, need_rows, peaks);
+    void*& fbuf = p->d_feat;
+    st = grow(p->device, &fbuf, &p->feat_cap, L.total);
+    if (st != SDRK_OK) return st;
+    char* base = static_cast<char*>(fbuf);
+    HIP_TRY(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
+    st = sdrk_frame_features_device(p, p->d_in, n_frames, frame_stride,
+                                    need_rows ? reinterpret_cast<float*>(base + L.rows_off) : nullptr, rank, gamma,
+                                    min_distance, max_peaks, reinterpret_cast<double*>(base + L.stats_off),
+                                    reinterpret_cast<double*>(base + L.thr_off),
+                                    peaks ? reinterpret_cast<int32_t*>(base + L.idx_off) : nullptr,
+                                    peaks ? reinterpret_cast<int32_t*>(base + L.cnt_off) : nullptr, nullptr);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipMemcpyAsync(out_stats, base + L.stats_off, n_frames * 16 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if (out_thr) HIP_TRY(hipMemcpyAsync(out_thr, base + L.thr_off, n_frames * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if (peaks) {
+        HIP_TRY(hipMemcpyAsync(out_idx, base + L.idx_off, n_frames * (size_t)max_peaks * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipMemcpyAsync(out_count, base + L.cnt_off, n_frames * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    }
+    if (need_rows)
+        HIP_TRY(hipMemcpyAsync(out_db, base + L.rows_off, n_frames * nfft * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return fused_check(p);
 }
 
 /* ---- waterfall ring ------------------------------------------------------ */
@@ -1007,6 +1165,7 @@ int sdrk_waterfall_destroy(sdrk_waterfall* wf) {
         (void)hipStreamDestroy(wf->stream);
     }
     if (wf->d_ring) (void)hipFree(wf->d_ring);
+    if (wf->d_dec) (void)hipFree(wf->d_dec);
     delete wf;
     return SDRK_OK;
 }
@@ -1125,12 +1284,12 @@ int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_row
     const size_t L = (size_t)wf->maxlen;
     const size_t start = (wf->head + L - rows % L) % L;
     const size_t bins = (size_t)(wf->nfft / factor);
-    DevBuf tmp;
-    HIP_TRY(hipMalloc(&tmp.p, rows * bins * sizeof(float)));
+    int st = grow(wf->device, &wf->d_dec, &wf->dec_cap, rows * bins * sizeof(float));
+    if (st != SDRK_OK) return st;
     hipError_t e = sdrk::launch_decimate_rows(wf->d_ring, wf->nfft, wf->maxlen, (int)start, (int)rows, factor, mode,
-                                              static_cast<float*>(tmp.p), wf->stream);
+                                              static_cast<float*>(wf->d_dec), wf->stream);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "decimate launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(out, tmp.p, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->stream));
+    HIP_TRY(hipMemcpyAsync(out, wf->d_dec, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->stream));
     HIP_TRY(hipStreamSynchronize(wf->stream));
     *n_rows = rows;
     return SDRK_OK;

@@ -53,30 +53,29 @@ def percentile_rank(n: int, q: float) -> int:
     return int(np.floor(np.float32(n - 1) * (np.float32(q) / np.float32(100))))
 
 
-def _features_from_device(ptr, on_device: bool, n_rows: int, nfft: int, freqs, device: int,
-                          percentile: float, max_peaks: int) -> List[dict]:
-    stats = np.empty((n_rows, _STATS), dtype=np.float64)
-    rank = percentile_rank(nfft, percentile)
-    check(lib().sdrk_row_stats(device, ptr, int(on_device), ctypes.c_size_t(n_rows), nfft, rank,
-                               stats.ctypes.data_as(c_void_p)))
+def percentile_gamma(n: int, q: float) -> np.float32:
+    """numpy.percentile's float32 interpolation weight for the q-th percentile of n values."""
+    vi = np.float32(n - 1) * (np.float32(q) / np.float32(100))
+    return np.float32(vi - np.floor(vi))
+
+
+def adaptive_threshold(max_db: np.float32, noise_floor_db32: np.float32) -> float:
+    """classifier.py:46,55 — ``max(noise_floor + 5, max - 0.9*snr + 5)`` with the dtype rules numpy applies in the
+    reference (float32 row statistics, NEP-50 weak python scalars).  The device computes the same value next to
+    the rows (row_features_core.h); tests assert the two agree to the bit."""
+    noise_floor_db = float(noise_floor_db32)                               # :181
+    snr_db = float(max_db - np.float32(noise_floor_db))                    # :46 (float32 - weak python float)
+    second = (max_db - np.float32(0.9 * snr_db)) + np.float32(5.0)         # :55, float32 under NEP 50
+    first = noise_floor_db + 5.0
+    # python max(first, second): `second > first` is evaluated in float32 (first is a weak python float)
+    return float(second) if second > np.float32(first) else first
+
+
+def _assemble(stats, thr, idx, cnt, nfft: int, freqs, percentile: float, max_peaks: int) -> List[dict]:
+    """Per-row dicts from the packed device results."""
+    n_rows = stats.shape[0]
     mx32 = stats[:, 0].astype(np.float32)
     nf32 = _percentile_from_order_stats(nfft, percentile, stats[:, 1], stats[:, 2])
-    thr = np.empty(n_rows, dtype=np.float64)
-    snr = np.empty(n_rows, dtype=np.float64)
-    for r in range(n_rows):
-        noise_floor_db = float(nf32[r])                                   # :181
-        snr_db = float(mx32[r] - np.float32(noise_floor_db))               # :46 (float32 - weak python float)
-        second = (mx32[r] - np.float32(0.9 * snr_db)) + np.float32(5.0)    # :55, float32 under NEP 50
-        first = noise_floor_db + 5.0
-        # python max(first, second): `second > first` is evaluated in float32 (first is a weak python float)
-        thr[r] = float(second) if second > np.float32(first) else first
-        snr[r] = snr_db
-    min_distance = max(3, nfft // 300)                                     # :56
-    idx = np.empty((n_rows, max_peaks), dtype=np.int32)
-    cnt = np.empty(n_rows, dtype=np.int32)
-    check(lib().sdrk_row_peaks(device, ptr, int(on_device), ctypes.c_size_t(n_rows), nfft,
-                               thr.ctypes.data_as(c_void_p), min_distance, max_peaks,
-                               idx.ctypes.data_as(c_void_p), cnt.ctypes.data_as(c_void_p)))
     f = None if freqs is None else np.asarray(freqs, dtype=np.float64)
     out = []
     for r in range(n_rows):
@@ -87,10 +86,10 @@ def _features_from_device(ptr, on_device: bool, n_rows: int, nfft: int, freqs, d
             "max_db": float(mx32[r]),
             "argmax": int(s[14]),
             "noise_floor_db": float(nf32[r]),
-            "snr_db": float(snr[r]),
+            "snr_db": float(mx32[r] - nf32[r]),                                        # :46
             "spectral_flatness": float(np.clip(np.exp(s[6]) / s[7], 0.0, 1.0)),      # :186-189
             "spectral_kurtosis": 0.0 if sigma < 1e-9 else float(s[5] / (s[4] * s[4])),  # :195-198
-            "adaptive_threshold_db": float(thr[r]),
+            "adaptive_threshold_db": float(thr[r]),                                   # :55, formed on the device
             "peak_idx": peaks,
             "peak_count": int(cnt[r]),
             "occupied_bins_3db": (int(s[8]), int(s[9])),
@@ -112,24 +111,43 @@ def _features_from_device(ptr, on_device: bool, n_rows: int, nfft: int, freqs, d
     return out
 
 
+def _result_arrays(n_rows: int, max_peaks: int):
+    return (np.empty((n_rows, _STATS), dtype=np.float64), np.empty(n_rows, dtype=np.float64),
+            np.empty((n_rows, max_peaks), dtype=np.int32), np.empty(n_rows, dtype=np.int32))
+
+
 def row_features(power_db, freqs=None, *, device: int = 0, percentile: float = 20.0, max_peaks: int = 4096):
-    """Features of one ``power_db`` row ``(N,)`` -> dict, or of rows ``(R, N)`` -> list of dicts."""
+    """Features of one ``power_db`` row ``(N,)`` -> dict, or of rows ``(R, N)`` -> list of dicts.  One kernel launch
+    that reads each row once (``sdrk_row_features``); ``power_db`` may be a host array or ``(device_pointer, n_rows,
+    nfft)`` for rows already in HBM."""
     _ffi.require_device(device)
-    rows = np.ascontiguousarray(np.asarray(power_db, dtype=np.float32))
-    one = rows.ndim == 1
-    if one:
-        rows = rows.reshape(1, -1)
-    if rows.ndim != 2 or rows.shape[1] < 1:
-        raise ValueError(f"expected (N,) or (R, N) rows, got {rows.shape}")
-    res = _features_from_device(rows.ctypes.data_as(c_void_p), False, rows.shape[0], rows.shape[1], freqs, device,
-                                percentile, max_peaks)
+    if isinstance(power_db, tuple):
+        ptr, n_rows, nfft = c_void_p(int(power_db[0])), int(power_db[1]), int(power_db[2])
+        on_device, one = True, False
+    else:
+        rows = np.ascontiguousarray(np.asarray(power_db, dtype=np.float32))
+        one = rows.ndim == 1
+        if one:
+            rows = rows.reshape(1, -1)
+        if rows.ndim != 2 or rows.shape[1] < 1:
+            raise ValueError(f"expected (N,) or (R, N) rows, got {rows.shape}")
+        ptr, (n_rows, nfft), on_device = rows.ctypes.data_as(c_void_p), rows.shape, False
+    stats, thr, idx, cnt = _result_arrays(n_rows, max_peaks)
+    check(lib().sdrk_row_features(device, ptr, int(on_device), ctypes.c_size_t(n_rows), nfft,
+                                  percentile_rank(nfft, percentile), ctypes.c_float(float(percentile_gamma(nfft, percentile))),
+                                  max(3, nfft // 300), max_peaks,                                   # :56
+                                  stats.ctypes.data_as(c_void_p), thr.ctypes.data_as(c_void_p),
+                                  idx.ctypes.data_as(c_void_p), cnt.ctypes.data_as(c_void_p)))
+    res = _assemble(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
     return res[0] if one else res
 
 
 def frame_features(samples, sample_rate: float, center_freq: float, *, window=None, eps: float = 1e-12,
-                   device: int = 0, percentile: float = 20.0, max_peaks: int = 4096):
-    """IQ frame(s) -> features, rows staying in HBM: the transform (streamer.py:119,121) writes its
-    rows to a device buffer and only the per-row scalars and peak indices come back."""
+                   device: int = 0, percentile: float = 20.0, max_peaks: int = 4096, return_rows: bool = False):
+    """IQ frame(s) -> features without the rows leaving the device (streamer.py:119,121 then classifier.py:163-212).
+    For 4096-sample frames — the reference's buffer size — the reductions are the epilogue of the transform kernel
+    itself and the row exists only on chip; other lengths run the transform and one single-read reduction launch.
+    ``return_rows=True`` also returns the ``power_db`` rows (then they are written once and copied back)."""
     from .spectrum import _as_c64, _cached_plan, freq_axis
     x = _as_c64(samples)
     one = x.ndim == 1
@@ -138,17 +156,18 @@ def frame_features(samples, sample_rate: float, center_freq: float, *, window=No
     n_rows, nfft = x.shape
     plan = _cached_plan(nfft, window, eps, True, device)
     freqs = freq_axis(nfft, sample_rate, center_freq)
-    d_in, d_out = c_void_p(), c_void_p()
-    check(lib().sdrk_dev_alloc(device, x.nbytes, ctypes.byref(d_in)))
-    try:
-        check(lib().sdrk_dev_alloc(device, n_rows * nfft * 4, ctypes.byref(d_out)))
-        try:
-            check(lib().sdrk_memcpy_h2d(device, d_in, x.ctypes.data_as(c_void_p), x.nbytes))
-            plan.exec_device(d_in.value, n_rows, d_out.value)
-            plan.sync()
-            res = _features_from_device(d_out, True, n_rows, nfft, freqs, device, percentile, max_peaks)
-        finally:
-            lib().sdrk_dev_free(device, d_out)
-    finally:
-        lib().sdrk_dev_free(device, d_in)
-    return res[0] if one else res
+    stats, thr, idx, cnt = _result_arrays(n_rows, max_peaks)
+    rows = np.empty((n_rows, nfft), dtype=np.float32) if return_rows else None
+    with plan._lock:
+        check(lib().sdrk_frame_features_host(plan.handle, x.ctypes.data_as(c_void_p), ctypes.c_size_t(n_rows),
+                                             ctypes.c_size_t(nfft), percentile_rank(nfft, percentile),
+                                             ctypes.c_float(float(percentile_gamma(nfft, percentile))),
+                                             max(3, nfft // 300), max_peaks,
+                                             stats.ctypes.data_as(c_void_p), thr.ctypes.data_as(c_void_p),
+                                             idx.ctypes.data_as(c_void_p), cnt.ctypes.data_as(c_void_p),
+                                             rows.ctypes.data_as(c_void_p) if rows is not None else None))
+    res = _assemble(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
+    res = res[0] if one else res
+    if return_rows:
+        return res, (rows[0] if one else rows)
+    return res

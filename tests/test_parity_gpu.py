@@ -517,17 +517,69 @@ def test_row_features_other_sizes_vs_oracle(pkg):
         assert abs(got["spectral_kurtosis"] - ref["spectral_kurtosis"]) <= 1e-9 * ref["spectral_kurtosis"]
 
 
-def test_frame_features_rows_stay_on_device(pkg):
+def _features_equal(a, b):
+    for key in a:
+        if key == "peak_idx":
+            assert np.array_equal(a[key], b[key])
+        else:
+            assert a[key] == b[key], key
+
+
+@pytest.mark.parametrize("n,window", [(4096, None), (4096, "hann"), (1024, None), (65536, "hann")])
+def test_frame_features_rows_stay_on_device(pkg, n, window):
+    """IQ -> features with the rows on the device: N = 4096 runs the reductions as the epilogue of the transform
+    (fft4096_features.hip, the row never leaves LDS), other lengths the transform plus one single-read reduction
+    launch.  Checked against the oracle's restatement of the classifier helpers on the rows the device produced,
+    and the rows themselves against the transform's usual parity bar."""
     from sdr_iq_visualizer_amd import features, synth
-    x = (synth.synth_iq(3, 0, 4, 4096) * np.float32(0.05) + synth.tone(4096, 700.0, 300.0)).astype(np.complex64)
-    got = features.frame_features(x, 1_000_000, 2_400_000_000)
-    rows = pkg.spectrum_db(x)                                       # same kernel -> same float32 rows
-    freqs = cpu_ref.freq_axis(4096, 1_000_000, 2_400_000_000)
-    for r in range(4):
+    nf = 5
+    x = (synth.synth_iq(3, 0, nf * n // 4096 if n >= 4096 else nf, 4096).reshape(-1)[: nf * n].reshape(nf, n) * np.float32(0.05)
+         + synth.tone(n, 0.17 * n, 300.0)).astype(np.complex64)
+    got, rows = features.frame_features(x, 1_000_000, 2_400_000_000, window=window, return_rows=True)
+    blind = features.frame_features(x, 1_000_000, 2_400_000_000, window=window)      # rows not even written
+    w = None if window is None else np.hanning(n)
+    assert_db_parity(rows, cpu_ref.spectrum_db(x, window=w), what=f"rows N={n}")
+    freqs = cpu_ref.freq_axis(n, 1_000_000, 2_400_000_000)
+    for r in range(nf):
+        _features_equal(got[r], blind[r])
         ref = cpu_ref.row_features(freqs, rows[r])
-        assert got[r]["noise_floor_db"] == ref["noise_floor_db"] and got[r]["snr_db"] == ref["snr_db"]
-        assert np.array_equal(got[r]["peak_idx"], ref["peak_idx"]) and got[r]["argmax"] == 2048 + 700
-        assert got[r]["bandwidth_hz_20db"] == ref["bandwidth_hz_20db"]
+        for key in ("noise_floor_db", "snr_db", "bandwidth_hz_3db", "bandwidth_hz_10db", "bandwidth_hz_20db",
+                    "adaptive_threshold_db", "peak_spacing_std_hz"):
+            assert got[r][key] == ref[key], (n, r, key)
+        assert np.array_equal(got[r]["peak_idx"], ref["peak_idx"]) and got[r]["argmax"] == n // 2 + int(0.17 * n)
+        assert abs(got[r]["spectral_flatness"] - ref["spectral_flatness"]) <= 1e-9
+        assert abs(got[r]["spectral_kurtosis"] - ref["spectral_kurtosis"]) <= 1e-9 * ref["spectral_kurtosis"]
+        # the threshold the device formed equals the host restatement of classifier.py:46,55 to the bit
+        assert got[r]["adaptive_threshold_db"] == features.adaptive_threshold(np.float32(got[r]["max_db"]),
+                                                                              np.float32(got[r]["noise_floor_db"]))
+    one = features.frame_features(x[0], 1_000_000, 2_400_000_000, window=window)
+    _features_equal(one, got[0])
+
+
+def test_row_features_special_rows(pkg):
+    """Edge cases of the reductions: the all-zero frame's -240 dB row (every value equal: sigma 0, flatness 1,
+    no peaks), rows with -inf (eps = 0) and an all-NaN row (empty band sentinels -> 0 Hz, as the reference)."""
+    from sdr_iq_visualizer_amd import features
+    freqs = cpu_ref.freq_axis(4096, 1e6, 0.0)
+    flat = np.full(4096, np.float32(-240.00002), dtype=np.float32)
+    got = features.row_features(flat, freqs)
+    ref = cpu_ref.row_features(freqs, flat)
+    assert got["peak_count"] == 0 and got["spectral_kurtosis"] == 0.0 and got["noise_floor_db"] == ref["noise_floor_db"]
+    assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= 1e-9 and got["bandwidth_hz_3db"] == ref["bandwidth_hz_3db"]
+    holes = np.linspace(-50, 10, 4096).astype(np.float32)
+    holes[::7] = -np.inf
+    got, ref = features.row_features(holes, freqs), cpu_ref.row_features(freqs, holes)
+    assert got["noise_floor_db"] == ref["noise_floor_db"] and got["bandwidth_hz_20db"] == ref["bandwidth_hz_20db"]
+    assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= 1e-9
+    nan_row = np.full(64, np.nan, dtype=np.float32)
+    got = features.row_features(nan_row, cpu_ref.freq_axis(64, 1e6, 0.0))
+    assert got["bandwidth_hz_3db"] == 0.0 and got["peak_count"] == 0
+    # rows longer than the LDS staging limit are scanned in place
+    long_row = (np.random.default_rng(5).standard_normal(1 << 17) * 6).astype(np.float32)
+    fl = cpu_ref.freq_axis(1 << 17, 1e6, 0.0)
+    got, ref = features.row_features(long_row, fl), cpu_ref.row_features(fl, long_row)
+    assert got["noise_floor_db"] == ref["noise_floor_db"] and np.array_equal(got["peak_idx"], ref["peak_idx"])
+    assert got["adaptive_threshold_db"] == ref["adaptive_threshold_db"]
 
 
 def test_waterfall_decimated_readout(pkg):
