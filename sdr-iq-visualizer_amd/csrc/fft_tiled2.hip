@@ -1,5 +1,5 @@
-// fft_tiled2.hip — frames of N = A * M samples, 2^15 <= N <= 2^20, in TWO tiled passes whose
-// sub-transforms (A, M <= 1024 points) run entirely in registers + LDS (fft_lds_core.h):
+// fft_tiled2.hip — frames of N = A * M samples, 2^15 <= N <= 2^22, in TWO tiled passes whose
+// sub-transforms (A, M <= 2048 points) run entirely in registers + LDS (fft_lds_core.h):
 // window -> FFT -> fftshift -> 20*log10(|X|+eps)   (app/sdr/streamer.py:119,121); the
 // waterfall sizes of BASELINE.json configs 3 (N = 65536) and 5 (N = 2^20).
 //
@@ -8,12 +8,13 @@
 //
 //   col pass   tile = 16 adjacent m x all A values of n3 (stride M): DFT-A per column, sixteen
 //              columns interleaved in LDS (lanes run along m: 128-byte segments in and out),
-//              times W_N^(m k3) = t1T[tau][m] * t2[m][q]  (k3 = tau + (A/16) q)   -> scratch[k3][m]
+//              times W_N^(m k3) = t1T[tau][m] * t2[m][q]  (k3 = tau + (A/16) q)   -> scratch (k3, m), stored
+//              in 16 x 16 squares (scratch_index below)
 //   row pass   tile = 16 adjacent k3 rows x M (each row contiguous): DFT-M per row, fftshift
 //              (km + M/2), log epilogue, then a 16 x M transpose through LDS so that the stores
 //              X[A km + k3] run along k3 (64-byte segments)
-// 28 B/sample of traffic (8 in, 8+8 scratch, 4 out) instead of the 44 of the three-pass form this
-// replaces for N > 65536; the scratch is processed in chunks that stay in the Infinity Cache.
+// 28 B/sample of traffic (8 in, 8+8 scratch, 4 out); the scratch is processed in chunks that stay in the
+// 256 MiB Infinity Cache between the pass that writes them and the pass that reads them.
 #include "fft_lds_core.h"
 
 namespace sdrk {
@@ -23,19 +24,9 @@ namespace sdrk {
 // in 16 x 16 element squares.  Stored as [k3/16][m/16][k3%16][m%16] (2 KiB squares, row tiles contiguous)
 // the col pass writes 2 KiB runs (512 B per wave instruction) instead of the 128-byte pieces at M*8-byte
 // stride a plain [k3][m] matrix costs it, and the row pass reads its 16 x M tile as one contiguous block.
-#ifndef T2_BLOCKED
-#define T2_BLOCKED 1
-#endif
-#ifndef T2_ST_AUX
-#define T2_ST_AUX 0   // cache policy of the scratch stores (0 default, 2 nt)
-#endif
 // element index of (k3, m) inside one frame's scratch
 __device__ __forceinline__ int scratch_index(int k3, int m, int M) {
-#if T2_BLOCKED
     return (((k3 >> 4) * (M >> 4) + (m >> 4)) << 8) + ((k3 & 15) << 4) + (m & 15);
-#else
-    return k3 * M + m;
-#endif
 }
 
 // W = tile width in columns (16, or 8 for A = 2048 so that the tile fits the LDS).
@@ -97,13 +88,8 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
         const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + f * frame_stride, live ? (unsigned)(nfft * 8) : 0u);
         const int e0 = tau * M + m;          // element (n3 = tau, m)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-#ifdef T2X_NOLOAD
-            x[q] = v2f{(float)(e0 + q), 1.0f};
-#else
+        for (int q = 0; q < 16; ++q)
             x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, 2));
-#endif
-        }
     };
     auto store = [&](size_t f, int m, const cf (&v)[16], const cf (&bw)[16]) {
         const __amdgpu_buffer_rsrc_t ro = frame_rsrc(scratch + f * nfft, (unsigned)(nfft * 8));
@@ -115,11 +101,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
             const cf z = cmul(v[rev16(q)], bw[q]);
             const v2f sv = {z.x, z.y};
             const int u = scratch_index(T * q, 0, M);
-#ifdef T2X_NOSTORE
-            asm volatile("" :: "v"(sv.x), "v"(sv.y), "s"(u), "v"(so));
-#else
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, u * 8, T2_ST_AUX);
-#endif
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, u * 8, 0);
         }
     };
 
@@ -191,78 +173,121 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
 #define COL_TILE_W(LOG2A) ((LOG2A) == 11 ? 8 : ((LOG2A) == 10 ? SDRK_COL_W1024 : ((LOG2A) == 8 ? SDRK_COL_W256 : 16)))
 #define ROW_TILE_R(LOG2M) ((LOG2M) == 11 ? 8 : 16)
 
-// ROWS = rows per tile (16, or 8 for M = 2048 so that the tile fits the LDS)
-template <int LOG2M, int EPILOGUE, int ROWS>
-__global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS, (LdsCfg<LOG2M>::T * ROWS >= 512 ? 4 : 3)) void row_pass_kernel(
+// ROWS = rows per tile (16, or 8 for M = 2048 so that the tile fits the LDS).
+// NV = 16-point sets per thread (fft_lds_core.h): 1, or 2 for M >= 1024, where one tile fills the LDS and a CU
+// holds a single workgroup.  With 1024 threads that workgroup is capped at 128 VGPRs and runs load -> transform ->
+// store strictly in sequence (measured at N = 2^20: 4.4 TB/s of streamed bytes against 5.9 for M = 256, where four
+// workgroups per CU overlap each other).  With NV = 2 the same tile takes 512 threads = two waves per SIMD and up
+// to 256 VGPRs each, enough to keep the NEXT tile's 32 loads per thread in flight across the current tile's
+// passes (the software pipeline of the col pass above).
+template <int LOG2M, int EPILOGUE, int ROWS, int NV>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS / NV, (NV > 1 ? 2 : (LdsCfg<LOG2M>::T * ROWS >= 512 ? 4 : 3))) void row_pass_kernel(
     const float2* __restrict__ scratch, void* __restrict__ out_raw, size_t n_frames, int A,
     const float2* __restrict__ twM, float eps, int shift) {
     using C = LdsCfg<LOG2M>;
-    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0;
+    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, TR = T / NV;
+    constexpr bool PREFETCH = NV > 1;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 16 rows x SLOT, reused for the transpose
     const int tid = threadIdx.x;
-    const int fr = tid / T, tau = tid - fr * T;
+    const int fr = tid / TR, rt = tid - fr * TR;
     float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
-    LdsTw<LOG2M> tw;
-    lds_tw_init<LOG2M>(tw, twM, tau);
+    LdsTw<LOG2M> tw[NV];
+#pragma unroll
+    for (int s = 0; s < NV; ++s) lds_tw_init<LOG2M>(tw[s], twM, rt + TR * s);
     const size_t nfft = (size_t)A * M;
     const int tiles = A / ROWS;
     const size_t items = n_frames * (size_t)tiles;
     const int xor_q = shift ? 8 : 0;
-    constexpr int WGT = T * ROWS;   // threads
+    constexpr int WGT = TR * ROWS;   // threads
 
+    // the 16 NV loads of one tile.  Rows k3_0 .. k3_0+ROWS-1: the descriptor covers the 16-row band they lie in
+    // (for ROWS = 8 the tile is half of it; zero-sized when there is no such item: the loads return zeros without
+    // touching memory); element (k3_0 + fr, m = tau_s + T c): lane part from (k3 & 15, tau_s), uniform part from T c
+    // PART of NPARTS: which of the 16 NV loads to issue (all of them when NPARTS == 1)
+    auto issue_part = [&](size_t it, v2f (&x)[NV][16], int part, int nparts) {
+        const bool live = it < items;
+        const size_t f = live ? it / tiles : 0;
+        const int k3_0 = live ? (int)(it - f * tiles) * ROWS : 0;
+        const int band = k3_0 & ~15;
+        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)band * M, live ? (unsigned)(16 * M * 8) : 0u);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int e0 = scratch_index((k3_0 & 15) + fr, rt + TR * s, M);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if ((s * 16 + c) * nparts / (16 * NV) != part) continue;
+                x[s][c] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, c * T, M) * 8, 0));
+            }
+        }
+    };
+    auto issue = [&](size_t it, v2f (&x)[NV][16]) { issue_part(it, x, 0, 1); };
+    // issue points of the prefetch: the loop top and every hook of the transform (fft_lds_core.h)
+    constexpr int NPARTS = PREFETCH ? 1 + lds_core_hooks<LOG2M, NV>() : 1;
+
+    v2f xa[NV][16], xb[NV][16];
+    if (PREFETCH) issue(blockIdx.x, xa);
     for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
         const size_t f = it / tiles;
         const int k3_0 = (int)(it - f * tiles) * ROWS;
-        // rows k3_0 .. k3_0+ROWS-1: the descriptor covers the 16-row band they lie in (for ROWS = 8 the tile is
-        // half of it); element (k3_0 + fr, m = tau + T c): lane part from (k3 & 15, tau), uniform part from T c
-        const int band = k3_0 & ~15;
-        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)band * M, (unsigned)(16 * M * 8));
-        const int e0 = scratch_index((k3_0 & 15) + fr, tau, M);
-        cf v[16];
+        const size_t nxt = it + gridDim.x;
+        if (PREFETCH) issue_part(nxt, xb, 0, NPARTS);
+        else issue(it, xa);
+        cf v[NV][16];
 #pragma unroll
-        for (int i = 0; i < C0; ++i)
+        for (int s = 0; s < NV; ++s)
 #pragma unroll
-            for (int j = 0; j < R0; ++j) {
-                const v2f t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, 0));
-                v[i * R0 + j] = cf{t.x, t.y};
-            }
-        lds_fft_core<LOG2M, 1>(v, lds, 0, tau, tw);
+            for (int i = 0; i < C0; ++i)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) v[s][i * R0 + j] = cf{xa[s][i + C0 * j].x, xa[s][i + C0 * j].y};
+        lds_fft_core_nv<LOG2M, 1, NV>(v, lds, 0, rt, tw, [&](int k) {
+            if (PREFETCH) issue_part(nxt, xb, k + 1, NPARTS);
+        });
         __syncthreads();  // all rows are through their last LDS reads: the buffer becomes the transpose tile
         if (EPILOGUE == EPI_LOGPSD) {
             float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][ROWS + 1]
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const cf z = v[rev16(q)];
-                tile[(tau + T * (q ^ xor_q)) * (ROWS + 1) + fr] = logpsd_db(z.x, z.y, eps);
-            }
+            for (int s = 0; s < NV; ++s)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const cf z = v[s][rev16(q)];
+                    tile[(rt + TR * s + T * (q ^ xor_q)) * (ROWS + 1) + fr] = logpsd_db(z.x, z.y, eps);
+                }
             __syncthreads();
             const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float*>(out_raw) + f * nfft + k3_0,
                                                          (unsigned)((nfft - k3_0) * 4));
-            // element e = tid + WGT i of the ROWS x M tile: row r = e % ROWS (lanes), km = e / ROWS = tid / ROWS + T i
+            // element e = tid + WGT i of the ROWS x M tile: row r = e % ROWS (lanes), km = e / ROWS = tid / ROWS + TR i
             const int r = tid & (ROWS - 1), km0 = tid / ROWS;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float val = tile[(km0 + T * i) * (ROWS + 1) + r];
+            for (int i = 0; i < 16 * NV; ++i) {
+                const float val = tile[(km0 + TR * i) * (ROWS + 1) + r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, (km0 * A + r) * 4,
-                                                      i * T * A * 4, 2);
+                                                      i * TR * A * 4, 2);
             }
         } else {
             float2* __restrict__ tile = lds_all;  // [km][ROWS + 1]
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const cf z = v[rev16(q)];
-                tile[(tau + T * (q ^ xor_q)) * (ROWS + 1) + fr] = make_float2(z.x, z.y);
-            }
+            for (int s = 0; s < NV; ++s)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const cf z = v[s][rev16(q)];
+                    tile[(rt + TR * s + T * (q ^ xor_q)) * (ROWS + 1) + fr] = make_float2(z.x, z.y);
+                }
             __syncthreads();
             float2* __restrict__ o = static_cast<float2*>(out_raw) + f * nfft + k3_0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 16 * NV; ++i) {
                 const int e = tid + WGT * i;
                 const int r = e & (ROWS - 1), km = e / ROWS;
                 o[(size_t)km * A + r] = tile[km * (ROWS + 1) + r];
             }
         }
         __syncthreads();  // tile reads done before the next item's exchanges
+        if (PREFETCH) {
+#pragma unroll
+            for (int s = 0; s < NV; ++s)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) xa[s][c] = xb[s][c];
+        }
     }
 }
 
@@ -317,10 +342,12 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
     return hipGetLastError();
 }
 
+#define ROW_NV(LOG2M) ((LOG2M) >= 10 ? 2 : 1)
+
 template <int LOG2M>
 static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, unsigned grid_cap) {
     using C = LdsCfg<LOG2M>;
-    constexpr int ROWS = ROW_TILE_R(LOG2M);
+    constexpr int ROWS = ROW_TILE_R(LOG2M), NV = ROW_NV(LOG2M);
     // LDS: the exchange area (ROWS x 17/16 M complex) or the complex transpose tile (M x (ROWS+1)), whichever is larger
     const size_t xch = (size_t)ROWS * C::SLOT, tile = (size_t)C::N * (ROWS + 1);
     const size_t lds_bytes = (xch > tile ? xch : tile) * sizeof(float2);
@@ -330,11 +357,11 @@ static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, u
     const float2* scratch = static_cast<const float2*>(a.d_scratch);
 #define SDRK_ROW(E)                                                                                              \
     do {                                                                                                         \
-        auto kern = row_pass_kernel<LOG2M, E, ROWS>;                                                                   \
+        auto kern = row_pass_kernel<LOG2M, E, ROWS, NV>;                                                          \
         static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                     \
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
         if (e0 != hipSuccess) return e0;                                                                         \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * ROWS), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * ROWS / NV), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps, \
                            a.shift);                                                                             \
     } while (0)
     if (a.epilogue == EPI_LOGPSD) SDRK_ROW(EPI_LOGPSD); else SDRK_ROW(EPI_COMPLEX);
