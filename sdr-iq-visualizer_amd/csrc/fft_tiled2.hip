@@ -39,7 +39,15 @@ __device__ __forceinline__ int scratch_index(int k3, int m, int M) {
 // stores, 2.4 ms without its loads and 3.8 ms with both — serialised phases).  Nothing in the loop body other
 // than the stream itself touches vector memory: vmcnt counts loads and stores in issue order on gfx950, so any
 // table load issued after the stores would make the wave wait for the store acknowledgements.
-template <int LOG2A, bool HAS_WINDOW, int W, bool FIXED>
+//
+// SH (FIXED only): overlapped frames cut from one stream (the STFT of config 3) share samples, and when the hop
+// is SH * T rows of the A x M view (SH = 8: 50 % overlap, SH = 4: 75 %), row n3 of frame f+1 is row n3 + SH*T of
+// frame f — the SAME thread's load number q + SH.  Each workgroup then walks a run of consecutive frames of its
+// tile position and loads only the SH new values per thread and frame, shifting the other 16 - SH down in
+// registers: the col pass reads every input sample once instead of 16/SH times (PMC, 384-frame chunks at 50 %
+// overlap: 150.8 MB fetched per launch before — L2 caught half of the re-reads — against 100.9 MB unique).
+// SH = 16: no reuse (packed frames or any other hop).
+template <int LOG2A, bool HAS_WINDOW, int W, bool FIXED, int SH>
 __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 ? 4 : 3)) void col_pass_kernel(
     const float2* __restrict__ iq, size_t frame_stride, float2* __restrict__ scratch, size_t n_frames, int M,
     const float* __restrict__ window, const float2* __restrict__ twA, const float2* __restrict__ t1T,
@@ -106,9 +114,13 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     };
 
     if (FIXED) {
-        size_t f;
-        int m;
-        locate(blockIdx.x, f, m);            // m is the same for every item of this workgroup
+        // tile position t = blockIdx % tiles; the gridDim / tiles workgroups of one position split the frames
+        // into contiguous runs
+        const int m = (int)(blockIdx.x % tiles) * W + fr;
+        const size_t lanes = gridDim.x / tiles, lane = blockIdx.x / tiles;
+        const size_t run = (n_frames + lanes - 1) / lanes;
+        const size_t f_begin = lane * run, f_end = f_begin + run < n_frames ? f_begin + run : n_frames;
+        if (f_begin >= f_end) return;
         float wreg[16];
         if (HAS_WINDOW) {
 #pragma unroll
@@ -116,10 +128,19 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
         }
         cf bw[16];
         factors(m, bw);
+        const int e0 = tau * M + m;          // element (n3 = tau, m)
+        // loads q >= q0 of frame f (zero-sized descriptor past the run: zeros, no memory access)
+        auto issue_from = [&](size_t f, v2f (&x)[16], int q0) {
+            const bool live = f < f_end;
+            const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + (live ? f : f_begin) * frame_stride, live ? (unsigned)(nfft * 8) : 0u);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q >= q0) x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, 2));
+        };
         v2f xa[16], xb[16];
-        issue(blockIdx.x, xa);
-        for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
-            issue(g + gridDim.x, xb);
+        issue_from(f_begin, xa, 0);
+        for (size_t f = f_begin; f < f_end; ++f) {
+            issue_from(f + 1, xb, 16 - SH);
             cf v[16];
 #pragma unroll
             for (int i = 0; i < C0; ++i)
@@ -129,9 +150,9 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
                     v[i * R0 + j] = HAS_WINDOW ? cf{xa[q].x * wreg[q], xa[q].y * wreg[q]} : cf{xa[q].x, xa[q].y};
                 }
             lds_fft_core<LOG2A, W>(v, lds_all, fr, tau, tw);
-            store(g / tiles, m, v, bw);
+            store(f, m, v, bw);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) xa[q] = xb[q];
+            for (int q = 0; q < 16; ++q) xa[q] = q < 16 - SH ? xa[q + SH] : xb[q];
         }
     } else {
         const __amdgpu_buffer_rsrc_t rw = frame_rsrc(window, HAS_WINDOW ? (unsigned)(nfft * 4) : 0u);
@@ -324,9 +345,16 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
     const float2* t1T = twA + 2048 + 2048;
     const float2* t2 = t1T + (size_t)(C::T) * M;
     float2* scratch = static_cast<float2*>(a.d_scratch);
-#define SDRK_COL(WIN, FIX)                                                                                       \
+    // overlapped frames: rows shared between consecutive frames (see the kernel's SH)
+    int sh = 16;
+    if (CAN_FIX && fixed && a.frame_stride % (size_t)M == 0) {
+        const size_t rows = a.frame_stride / (size_t)M;
+        if (rows == (size_t)C::T * 8) sh = 8;
+        else if (rows == (size_t)C::T * 4) sh = 4;
+    }
+#define SDRK_COL(WIN, FIX, SHV)                                                                                  \
     do {                                                                                                         \
-        auto kern = col_pass_kernel<LOG2A, WIN, W, FIX>;                                                         \
+        auto kern = col_pass_kernel<LOG2A, WIN, W, FIX, SHV>;                                                    \
         static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                     \
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
         if (e0 != hipSuccess) return e0;                                                                         \
@@ -334,9 +362,11 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
                            M, a.d_window, twA, t1T, t2);                                                            \
     } while (0)
     if (CAN_FIX && fixed) {
-        if (a.d_window) SDRK_COL(true, CAN_FIX); else SDRK_COL(false, CAN_FIX);
+        if (sh == 8) { if (a.d_window) SDRK_COL(true, CAN_FIX, (CAN_FIX ? 8 : 16)); else SDRK_COL(false, CAN_FIX, (CAN_FIX ? 8 : 16)); }
+        else if (sh == 4) { if (a.d_window) SDRK_COL(true, CAN_FIX, (CAN_FIX ? 4 : 16)); else SDRK_COL(false, CAN_FIX, (CAN_FIX ? 4 : 16)); }
+        else { if (a.d_window) SDRK_COL(true, CAN_FIX, 16); else SDRK_COL(false, CAN_FIX, 16); }
     } else {
-        if (a.d_window) SDRK_COL(true, false); else SDRK_COL(false, false);
+        if (a.d_window) SDRK_COL(true, false, 16); else SDRK_COL(false, false, 16);
     }
 #undef SDRK_COL
     return hipGetLastError();

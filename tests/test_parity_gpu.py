@@ -194,6 +194,44 @@ def test_stft_n65536_half_overlap(pkg):
     assert_db_parity(got, ref, what="stft 65536/32768")
 
 
+@pytest.mark.parametrize("n,hop_div,rows", [(65536, 2, 230), (65536, 4, 260), (32768, 2, 210), (32768, 4, 333),
+                                             (65536, 8, 200), (65536, 1, 130)])
+def test_stft_large_frames_register_reuse_of_overlapped_samples(pkg, n, hop_div, rows):
+    """Overlapped large frames (config 3's shape) with more frames than workgroup runs, so that the col pass
+    really walks consecutive frames of one tile position and reuses the shared samples from registers
+    (fft_tiled2.hip, SH = 8 at 50 % overlap, SH = 4 at 75 %); hop = N/8 and packed frames take the plain form.
+    Device-resident stream; first/last rows, run boundaries and random rows against the oracle."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, synth
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    hop = n // hop_div
+    L = n + (rows - 1) * hop
+    gen = (L + 4095) // 4096
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, gen * 4096 * 8, ctypes.byref(d_in)))
+    try:
+        _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_out)))
+        try:
+            _ffi.check(lib.sdrk_synth_fill(0, 606, 0, gen, 4096, d_in, None))
+            with SpectrumPlan(n, window="hann") as plan:
+                plan.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)
+                plan.sync()
+            stream = synth.synth_iq(606, 0, gen, 4096).reshape(-1)
+            rng = np.random.default_rng(n + hop_div)
+            picks = sorted({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 47, 48, 49, rows - 2, rows - 1} | set(int(v) for v in rng.integers(0, rows, 12)))
+            got = np.empty((len(picks), n), dtype=np.float32)
+            for i, r in enumerate(picks):
+                _ffi.check(lib.sdrk_memcpy_d2h(0, got[i].ctypes.data_as(ctypes.c_void_p),
+                                               ctypes.c_void_p(d_out.value + r * n * 4), n * 4))
+            frames = np.stack([stream[r * hop: r * hop + n] for r in picks])
+            assert_db_parity(got, cpu_ref.spectrum_db(frames, window=np.hanning(n)), what=f"N={n} hop=N/{hop_div}")
+        finally:
+            lib.sdrk_dev_free(0, d_out)
+    finally:
+        lib.sdrk_dev_free(0, d_in)
+
+
 # ---- waterfall ring --------------------------------------------------------------------
 
 def test_waterfall_matches_deque_semantics(pkg, golden):
