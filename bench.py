@@ -57,6 +57,8 @@ def parse_args():
                     help="budget for the all-cores leg (0 disables it; pure CPU, forked before any GPU runtime loads)")
     ap.add_argument("--parity-frames", type=int, default=1024,
                     help="random frames of the timed output checked against the oracle (SURVEY.md §8d: >= 1024)")
+    ap.add_argument("--placement-candidates", type=int, default=4,
+                    help="output-buffer placements probed for the resident pair (1 = plain allocation)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip configs 3/5, the numpy boundary and the feature-reduction legs")
     return ap.parse_args()
@@ -357,17 +359,22 @@ def feature_reductions(lib, _ffi, SpectrumPlan, features, dev, n_frames=1 << 18)
             out["fused_rows_also_written"] = {"ms": round(t * 1e3, 3), "rows_per_s": round(n_frames / t),
                                               "GBps": round(12 * n_frames * n / t / 1e9, 1)}
 
+            import numpy as np
+            host = {"stats": np.empty((n_frames, 16), dtype=np.float64), "thr": np.empty(n_frames, dtype=np.float64),
+                    "idx": np.empty((n_frames, max_peaks), dtype=np.int32), "cnt": np.empty(n_frames, dtype=np.int32)}
+            hp = {k: v.ctypes.data_as(ctypes.c_void_p) for k, v in host.items()}
+
             def separate():
                 plan.exec_device(bufs["iq"].value, n_frames, bufs["rows"].value)
                 plan.sync()
                 _ffi.check(lib.sdrk_row_features(dev, bufs["rows"], 1, n_frames, n, rank, ctypes.c_float(gamma),
-                                                 max(3, n // 300), max_peaks, host_stats.ctypes.data_as(ctypes.c_void_p),
-                                                 None, None, None))
+                                                 max(3, n // 300), max_peaks, hp["stats"], hp["thr"], hp["idx"], hp["cnt"]))
 
-            import numpy as np
-            host_stats = np.empty((n_frames, 16), dtype=np.float64)
             t = timed(separate)
-            out["transform_then_row_features_host_stats"] = {"ms": round(t * 1e3, 3), "rows_per_s": round(n_frames / t)}
+            out["transform_then_single_read_reduction"] = {
+                "ms": round(t * 1e3, 3), "rows_per_s": round(n_frames / t),
+                "what": "fft4096_kernel writes the rows, row_features_kernel reads them once (staged in LDS); "
+                        "includes the D2H of the per-row results (stats, threshold, 64 peak slots)"}
         return out
     finally:
         for b in bufs.values():
@@ -421,9 +428,16 @@ def main():
 
     frames = args.frames
     first_frame = rank * frames                     # config 4: GPU g owns [g*F, (g+1)*F)
+    # the resident IQ / row buffers, the rows placed by sdrk_dev_alloc_stream_pair (the streaming rate of a
+    # read+write pair depends on which two allocations are paired: DESIGN.md §4.1)
     d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
-    _ffi.check(lib.sdrk_dev_alloc(dev, frames * NFFT * 8, ctypes.byref(d_in)))
-    _ffi.check(lib.sdrk_dev_alloc(dev, frames * NFFT * 4, ctypes.byref(d_out)))
+    probe_ms, chosen = (ctypes.c_float * args.placement_candidates)(), ctypes.c_int(0)
+    _ffi.check(lib.sdrk_dev_alloc_stream_pair(dev, frames * NFFT * 8, frames * NFFT * 4, args.placement_candidates,
+                                              ctypes.byref(d_in), ctypes.byref(d_out), probe_ms, ctypes.byref(chosen)))
+    placement = {"candidates": args.placement_candidates, "probe_ms": [round(float(v), 4) for v in probe_ms],
+                 "chosen": int(chosen.value),
+                 "what": "output buffer chosen among candidates by a no-arithmetic 2:1 streaming probe over the "
+                         "pair (sdrk_dev_alloc_stream_pair); 1 candidate = plain allocation"}
     _ffi.check(lib.sdrk_synth_fill(dev, 1234, first_frame, frames, NFFT, d_in, None))
 
     plan = SpectrumPlan(NFFT, window=None if args.window == "rect" else args.window, device=dev)
@@ -568,6 +582,7 @@ def main():
                           "n": len(each_ms), "scope": "rank 0"},
             "parity_max_rel_err": parity,
             "parity_frames_checked": n_checked,
+            "placement": placement,
         }
         if tel is not None:
             line["telemetry"] = {"before": before, "during": tel.summary(), "after": after,

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -483,6 +484,85 @@ int sdrk_dev_free(int device, void* d_ptr) {
     if (st != SDRK_OK) return st;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(d_ptr));
+    return SDRK_OK;
+}
+
+int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, int candidates, void** d_in,
+                               void** d_out, float* probe_ms, int* chosen) {
+    if (!d_in || !d_out) return fail(SDRK_ERR_INVALID, "d_in or d_out is NULL");
+    *d_in = *d_out = nullptr;
+    if (chosen) *chosen = 0;
+    if (candidates < 1) candidates = 1;
+    if (candidates > 16) candidates = 16;
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    HIP_TRY(hipMalloc(d_in, in_bytes ? in_bytes : 1));
+    // probe = the no-arithmetic streaming kernel with the spectrum path's 2:1 traffic shape over the pair (its
+    // first 2^20 frame-equivalents: a short prefix mispredicts the intermediate levels); below 2^13
+    // frame-equivalents the levels do not separate, and nothing is tuned
+    size_t pf = in_bytes / 32768 < out_bytes / 16384 ? in_bytes / 32768 : out_bytes / 16384;
+    if (pf > ((size_t)1 << 20)) pf = (size_t)1 << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        while (candidates > 1 && (size_t)candidates * out_bytes + ((size_t)1 << 30) > free_b) --candidates;
+    }
+    if (pf < ((size_t)1 << 13)) candidates = 1;
+    std::vector<void*> cand((size_t)candidates, nullptr);
+    std::vector<float> ms((size_t)candidates, 0.0f);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t s = nullptr;
+    hipError_t e = hipSuccess;
+    if (candidates > 1) {
+        e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    }
+    int n_ok = 0;
+    for (int c = 0; c < candidates && e == hipSuccess; ++c) {
+        // earlier candidates stay allocated, so each new one lands somewhere else
+        if (hipMalloc(&cand[(size_t)c], out_bytes ? out_bytes : 1) != hipSuccess) {
+            (void)hipGetLastError();
+            cand[(size_t)c] = nullptr;
+            break;
+        }
+        ++n_ok;
+        if (candidates == 1) break;
+        float t[4];
+        for (int r = 0; r < 4 && e == hipSuccess; ++r) {
+            e = hipEventRecord(e0, s);
+            if (e == hipSuccess) e = sdrk::launch_stream_mix(*d_in, cand[(size_t)c], pf, prop.multiProcessorCount, s);
+            if (e == hipSuccess) e = hipEventRecord(e1, s);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&t[r], e0, e1);
+        }
+        if (e == hipSuccess) {
+            std::sort(t + 1, t + 4);       // one warm-up, median of three
+            ms[(size_t)c] = t[2];
+        }
+    }
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    int best = 0;
+    for (int c = 1; c < n_ok; ++c)
+        if (ms[(size_t)c] < ms[(size_t)best]) best = c;
+    if (e != hipSuccess || n_ok == 0) {
+        for (void* p : cand) if (p) (void)hipFree(p);
+        (void)hipFree(*d_in);
+        *d_in = nullptr;
+        if (e != hipSuccess) return fail(SDRK_ERR_HIP, "placement probe failed: %s", hipGetErrorString(e));
+        return fail(SDRK_ERR_NOMEM, "could not allocate %zu bytes for the output buffer", out_bytes);
+    }
+    for (int c = 0; c < n_ok; ++c) {
+        if (probe_ms) probe_ms[c] = ms[(size_t)c];
+        if (c != best) (void)hipFree(cand[(size_t)c]);
+    }
+    if (probe_ms) for (int c = n_ok; c < candidates; ++c) probe_ms[c] = 0.0f;
+    *d_out = cand[(size_t)best];
+    if (chosen) *chosen = best;
     return SDRK_OK;
 }
 

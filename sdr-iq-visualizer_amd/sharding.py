@@ -131,8 +131,8 @@ def distributed_spectrum_db(samples, *, window=None, eps: float = 1e-12, shift: 
     """One-process-per-GPU form.  Every rank passes the same ``(B, N)`` batch (or a
     lazily-indexable view of it); rank r transforms frames ``rank_range(B, r, W)``
     on its own GPU and rank ``dst`` returns the gathered ``(B, N)`` float32 array
-    (other ranks return ``None``).  The rank's GPU is ``device``, else ``LOCAL_RANK`` — it is used for the
-    transform and, under the nccl backend, for the tensor handed to the gather.  ``compute`` replaces the per-rank transform —
+    (other ranks return ``None``).  The rank's GPU is ``device``, else ``LOCAL_RANK``.  The gather moves host
+    arrays and therefore runs over a CPU (gloo) group, also when the job's backend is nccl.  ``compute`` replaces the per-rank transform —
     the CPU test-suite injects the oracle there to exercise the sharding and the
     gather under gloo without a GPU; the product default is the HIP path."""
     import torch
@@ -152,20 +152,41 @@ def distributed_spectrum_db(samples, *, window=None, eps: float = 1e-12, shift: 
     rows = compute(mine) if hi > lo else np.empty((0, nfft), dtype=np.float32)
     rows = np.ascontiguousarray(rows, dtype=np.float32)
 
-    # Host gather: pad every shard to the longest range so one gather suffices.
+    # Host gather: pad every shard to the longest range so one gather suffices.  The rows are host arrays and
+    # the destination is a host array, so the exchange runs over a CPU (gloo) group even when the job's default
+    # backend is nccl/RCCL — staging them through HBM only to copy them straight back would add two PCIe trips.
     longest = max(b - a for a, b in shard_ranges(n_frames, world))
     padded = np.zeros((longest, nfft), dtype=np.float32)
     padded[: hi - lo] = rows
     t = torch.from_numpy(padded)
-    if use_cuda:
-        # RCCL moves device tensors: stage on THIS rank's GPU (never torch's current device, which is
-        # cuda:0 in every rank unless the caller ran torch.cuda.set_device)
+    hgroup = _host_group(group) if use_cuda else group
+    if use_cuda and hgroup is None:
+        # no CPU group could be made: fall back to device tensors on THIS rank's GPU (never torch's current
+        # device, which is cuda:0 in every rank unless the caller ran torch.cuda.set_device)
         t = t.to(torch.device("cuda", int(device)))
+        hgroup = group
     bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    dist.gather(t, bucket, dst=dst, group=group)
+    dst_global = dst if group is None else dist.get_global_rank(group, dst)   # `dst` is a rank of `group`
+    dist.gather(t, bucket, dst=dst_global, group=hgroup)
     if rank != dst:
         return None
     out = np.empty((n_frames, nfft), dtype=np.float32)
     for r, (a, b) in enumerate(shard_ranges(n_frames, world)):
         out[a:b] = bucket[r][: b - a].cpu().numpy()
     return out
+
+
+_host_groups: dict = {}
+
+
+def _host_group(group):
+    """A gloo process group with the same ranks as ``group`` (created once, collectively), or None."""
+    import torch.distributed as dist
+    key = id(group) if group is not None else None
+    if key not in _host_groups:
+        try:
+            ranks = None if group is None else dist.get_process_group_ranks(group)
+            _host_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+        except Exception:  # pragma: no cover - backend not available
+            _host_groups[key] = None
+    return _host_groups[key]

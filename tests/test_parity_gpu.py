@@ -311,6 +311,40 @@ def test_host_pipeline_chunking_paths(pkg):
     assert_complex_parity(c[[0, 255, 256, 699]], np.fft.fft(x[[0, 255, 256, 699]].astype(np.complex128), axis=-1), rel=1e-5)
 
 
+def test_stream_pair_allocation_probes_and_returns_usable_buffers(pkg):
+    """sdrk_dev_alloc_stream_pair: the output of a resident in/out pair is picked among candidates by a streaming
+    probe.  Checks the contract, not the speed: every candidate was timed, the kept one is
+    one of them, both buffers work for a transform, tiny pairs are not probed."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, synth
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    nf, n = 1 << 14, 4096
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    ms, chosen = (ctypes.c_float * 3)(), ctypes.c_int(-1)
+    _ffi.check(lib.sdrk_dev_alloc_stream_pair(0, nf * n * 8, nf * n * 4, 3, ctypes.byref(d_in), ctypes.byref(d_out),
+                                              ms, ctypes.byref(chosen)))
+    try:
+        assert d_in.value and d_out.value and 0 <= chosen.value < 3
+        assert all(v > 0 for v in ms) and ms[chosen.value] == min(ms)
+        _ffi.check(lib.sdrk_synth_fill(0, 5, 0, nf, n, d_in, None))
+        with SpectrumPlan(n) as plan:
+            plan.exec_device(d_in.value, nf, d_out.value)
+            plan.sync()
+        row = np.empty(n, dtype=np.float32)
+        for f in (0, nf - 1):
+            _ffi.check(lib.sdrk_memcpy_d2h(0, row.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out.value + f * n * 4), n * 4))
+            assert_db_parity(row, cpu_ref.spectrum_db(synth.synth_iq(5, f, 1, n)[0]), what=f"frame {f}")
+    finally:
+        lib.sdrk_dev_free(0, d_in)
+        lib.sdrk_dev_free(0, d_out)
+    small = (ctypes.c_float * 4)()
+    _ffi.check(lib.sdrk_dev_alloc_stream_pair(0, 64 * n * 8, 64 * n * 4, 4, ctypes.byref(d_in), ctypes.byref(d_out), small, None))
+    assert d_in.value and d_out.value and list(small) == [0.0] * 4          # too small to matter: plain allocation
+    lib.sdrk_dev_free(0, d_in)
+    lib.sdrk_dev_free(0, d_out)
+
+
 def test_device_generator_bit_identical_to_numpy_mirror(pkg):
     import ctypes
     from sdr_iq_visualizer_amd import _ffi, synth
@@ -784,8 +818,10 @@ def test_config3_full_size_sampled_rows(pkg):
 
 def test_one_process_per_gpu_path_under_torchrun(pkg, tmp_path):
     """sharding.distributed_spectrum_db with the product transform under torch.distributed (backend "nccl" =
-    RCCL) — one rank here, since this box has one GPU; the frame-range arithmetic for more ranks is covered
-    by the gloo tests.  Launched the way the driver launches bench.py."""
+    RCCL), one rank per visible GPU (up to 4; one rank on a 1-GPU box — the frame-range arithmetic for more
+    ranks is covered by the gloo tests).  Launched the way the driver launches bench.py.  The ranks do NOT call
+    torch.cuda.set_device: the function has to pick its rank's GPU from LOCAL_RANK itself, and its host gather
+    runs over a gloo group next to the nccl one."""
     import subprocess
     import sys
     from tests.conftest import REPO
@@ -797,16 +833,20 @@ def test_one_process_per_gpu_path_under_torchrun(pkg, tmp_path):
         "import numpy as np\n"
         "from oracle import cpu_ref\n"
         "from sdr_iq_visualizer_amd import sharding, synth\n"
-        "torch.cuda.set_device(int(os.environ['LOCAL_RANK']))\n"
         "dist.init_process_group('nccl', device_id=torch.device('cuda', int(os.environ['LOCAL_RANK'])))\n"
         "x = synth.synth_iq(9, 0, 37, 4096)\n"
         "out = sharding.distributed_spectrum_db(x, window='hann')\n"
         "ref = cpu_ref.spectrum_db(x, window=np.hanning(4096))\n"
-        "mg, mr = 10.0 ** (out.astype(np.float64) / 20), 10.0 ** (ref.astype(np.float64) / 20)\n"
-        "err = float((np.abs(mg - mr) / mr.max(axis=-1, keepdims=True)).max())\n"
-        "assert out.shape == (37, 4096) and err <= 1e-5, err\n"
-        "dist.barrier(); dist.destroy_process_group(); print('rank ok', err)\n")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+        "if dist.get_rank() == 0:\n"
+        "    mg, mr = 10.0 ** (out.astype(np.float64) / 20), 10.0 ** (ref.astype(np.float64) / 20)\n"
+        "    err = float((np.abs(mg - mr) / mr.max(axis=-1, keepdims=True)).max())\n"
+        "    assert out.shape == (37, 4096) and err <= 1e-5, err\n"
+        "    print('rank ok', err)\n"
+        "else:\n"
+        "    assert out is None\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    nproc = max(1, min(pkg.device_count(), 4))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
