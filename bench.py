@@ -57,7 +57,7 @@ def parse_args():
                     help="budget for the all-cores leg (0 disables it; pure CPU, forked before any GPU runtime loads)")
     ap.add_argument("--parity-frames", type=int, default=1024,
                     help="random frames of the timed output checked against the oracle (SURVEY.md §8d: >= 1024)")
-    ap.add_argument("--placement-candidates", type=int, default=4,
+    ap.add_argument("--placement-candidates", type=int, default=6,
                     help="output-buffer placements probed for the resident pair (1 = plain allocation)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip configs 3/5, the numpy boundary and the feature-reduction legs")
@@ -428,19 +428,21 @@ def main():
 
     frames = args.frames
     first_frame = rank * frames                     # config 4: GPU g owns [g*F, (g+1)*F)
+    plan = SpectrumPlan(NFFT, window=None if args.window == "rect" else args.window, device=dev)
+
     # the resident IQ / row buffers, the rows placed by sdrk_dev_alloc_stream_pair (the streaming rate of a
-    # read+write pair depends on which two allocations are paired: DESIGN.md §4.1)
+    # read+write pair depends on which two allocations are paired: DESIGN.md §4.1); the probe is the plan's own
+    # transform, run before the warm-up on the not yet generated input (its values do not matter)
     d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
     probe_ms, chosen = (ctypes.c_float * args.placement_candidates)(), ctypes.c_int(0)
     _ffi.check(lib.sdrk_dev_alloc_stream_pair(dev, frames * NFFT * 8, frames * NFFT * 4, args.placement_candidates,
-                                              ctypes.byref(d_in), ctypes.byref(d_out), probe_ms, ctypes.byref(chosen)))
+                                              plan.handle, ctypes.byref(d_in), ctypes.byref(d_out), probe_ms,
+                                              ctypes.byref(chosen)))
     placement = {"candidates": args.placement_candidates, "probe_ms": [round(float(v), 4) for v in probe_ms],
                  "chosen": int(chosen.value),
-                 "what": "output buffer chosen among candidates by a no-arithmetic 2:1 streaming probe over the "
-                         "pair (sdrk_dev_alloc_stream_pair); 1 candidate = plain allocation"}
+                 "what": "output buffer chosen among candidates by timing the plan's transform over each pairing with "
+                         "the input buffer (sdrk_dev_alloc_stream_pair); 1 candidate = plain allocation"}
     _ffi.check(lib.sdrk_synth_fill(dev, 1234, first_frame, frames, NFFT, d_in, None))
-
-    plan = SpectrumPlan(NFFT, window=None if args.window == "rect" else args.window, device=dev)
 
     def barrier():
         plan.sync()

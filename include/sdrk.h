@@ -80,12 +80,13 @@ int sdrk_dev_free(int device, void* d_ptr);
  * two allocations are paired — read-only and write-only rates do not depend on the buffer, and the level is
  * stable for the life of the pair (csrc/tools/placeprobe.hip).  This call allocates the input,
  * then up to `candidates` outputs (earlier ones stay allocated meanwhile, so each lands elsewhere), times a
- * no-arithmetic 2:1 streaming kernel over a prefix of each pairing and keeps the fastest.  probe_ms (may be
- * NULL): `candidates` floats, the median probe time of each candidate (0 = not tried); chosen (may be NULL):
- * index kept.  Pairs too small for the effect to show are allocated without probing.  Free both with
- * sdrk_dev_free. */
+ * probe over each pairing and keeps the fastest.  The probe is `plan`'s own transform over the pair (packed
+ * frames; the input need not be initialised) or, with plan = NULL, a no-arithmetic kernel with the 2:1 traffic
+ * shape.  probe_ms (may be NULL): `candidates` floats, the median probe time of each candidate (0 = not tried);
+ * chosen (may be NULL): index kept.  Pairs too small for the effect to show (< 2^13 frame-equivalents of 4096
+ * samples) are allocated without probing.  Free both with sdrk_dev_free. */
 int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, int candidates,
-                               void** d_in, void** d_out, float* probe_ms, int* chosen);
+                               sdrk_plan* plan, void** d_in, void** d_out, float* probe_ms, int* chosen);
 int sdrk_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes);
 int sdrk_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes);
 

@@ -54,8 +54,8 @@ SYMBOLS = [
     ("sdrk_device_info", c_int, [c_int, c_char_p, c_size_t]),
     ("sdrk_dev_alloc", c_int, [c_int, c_size_t, POINTER(c_void_p)]),
     ("sdrk_dev_free", c_int, [c_int, c_void_p]),
-    ("sdrk_dev_alloc_stream_pair", c_int, [c_int, c_size_t, c_size_t, c_int, POINTER(c_void_p), POINTER(c_void_p),
-                                           POINTER(c_float), POINTER(c_int)]),
+    ("sdrk_dev_alloc_stream_pair", c_int, [c_int, c_size_t, c_size_t, c_int, c_void_p, POINTER(c_void_p),
+                                           POINTER(c_void_p), POINTER(c_float), POINTER(c_int)]),
     ("sdrk_memcpy_h2d", c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     ("sdrk_memcpy_d2h", c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     ("sdrk_plan_create", c_int,

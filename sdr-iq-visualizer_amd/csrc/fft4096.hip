@@ -38,10 +38,11 @@
 
 namespace sdrk {
 
-// FASTLOG: when every lane of the wave has |X| >= eps * 2^25 on all its 16 bins, |X| + eps rounds to |X|
-// and 20*log10(|X| + eps) = 10*log10(|X|^2): the square root and the add are skipped (wave-uniform branch;
-// any smaller value, zero or NaN in the wave takes the reference-order path).
-template <bool HAS_WINDOW, int EPILOGUE, bool FASTLOG, bool TWCHAIN>
+// (Tried and dropped, A/B on the same buffers: twiddles by product tree instead of LDS tables (neutral), a sqrt-free
+// log epilogue (1.5 % slower), and sending the row through LDS once more so that it leaves as four 16-byte stores
+// per thread instead of sixteen 4-byte ones (1.0-1.5 % slower: two more barriers per frame cost more than the
+// narrower stores do).)
+template <bool HAS_WINDOW, int EPILOGUE>
 __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     const float2* __restrict__ iq, size_t frame_stride, void* __restrict__ out_raw,
     size_t n_frames, const float* __restrict__ window, const float2* __restrict__ tw4096,
@@ -69,7 +70,6 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     __syncthreads();
 
     const int xor_k2 = shift ? 8 : 0;
-    const float fast_thresh = (eps * 33554432.0f) * (eps * 33554432.0f);  // (eps * 2^25)^2
     const int voff_in = tid * 8;
     constexpr int OUT_ELEM = (EPILOGUE == EPI_LOGPSD ? 4 : 8);
     const int voff_out = tid * OUT_ELEM;
@@ -108,38 +108,17 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
             for (int j = 0; j < 16; ++j) v[j] = v[j] * lds_win[tid + 256 * j];
 #endif
         }
-        f4k_transform<TWCHAIN>(v, lds, tw256, tw4k, A, tid);
+        f4k_transform(v, lds, tw256, tw4k, A, tid);
         // ---- epilogue + store: bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor) ----
         __amdgpu_buffer_rsrc_t w = frame_rsrc(
             static_cast<char*>(out_raw) + f * (size_t)(F4K_N * OUT_ELEM), F4K_N * OUT_ELEM);
         if (EPILOGUE == EPI_LOGPSD) {
-            bool fast = false;
-            float p[16], pmin;
-            if (FASTLOG) {
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 cf z = v[rev16(k2)];
-                p[k2] = fmaf(z.x, z.x, z.y * z.y);
-            }
-            pmin = fminf(fminf(fminf(p[0], p[1]), fminf(p[2], p[3])), fminf(fminf(p[4], p[5]), fminf(p[6], p[7])));
-            pmin = fminf(pmin, fminf(fminf(fminf(p[8], p[9]), fminf(p[10], p[11])),
-                                     fminf(fminf(p[12], p[13]), fminf(p[14], p[15]))));
-            // NaN compares false -> slow path, which propagates it like the reference does.
-            fast = __builtin_amdgcn_ballot_w64(!(pmin >= fast_thresh)) == 0;
-            }
-            if (FASTLOG && fast) {
-#pragma unroll
-                for (int k2 = 0; k2 < 16; ++k2)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, logpsd_db_fast(p[k2])), w,
-                                                          voff_out, (k2 ^ xor_k2) * 1024, F4K_NT);
-            } else {
-#pragma unroll
-                for (int k2 = 0; k2 < 16; ++k2) {
-                    cf z = v[rev16(k2)];
-                    float db = logpsd_db(z.x, z.y, eps);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, db), w, voff_out,
-                                                          (k2 ^ xor_k2) * 1024, F4K_NT);
-                }
+                float db = logpsd_db(z.x, z.y, eps);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, db), w, voff_out,
+                                                      (k2 ^ xor_k2) * 1024, F4K_NT);
             }
         } else {
 #pragma unroll
@@ -161,23 +140,13 @@ hipError_t launch_fft4096(const LaunchArgs& a) {
     dim3 g(grid), b(F4K_THREADS);
     const float2* iq = static_cast<const float2*>(a.d_iq);
     const float2* tw = static_cast<const float2*>(a.d_twiddle);
-#define SDRK_LAUNCH(W, E, F)                                                                        \
-    do {                                                                                               \
-        if (a.tw_chain)                                                                                \
-            hipLaunchKernelGGL((fft4096_kernel<W, E, F, true>), g, b, 0, a.stream, iq, a.frame_stride,  \
-                               a.d_out, a.n_frames, a.d_window, tw, a.eps, a.shift);                   \
-        else                                                                                           \
-            hipLaunchKernelGGL((fft4096_kernel<W, E, F, false>), g, b, 0, a.stream, iq, a.frame_stride, \
-                               a.d_out, a.n_frames, a.d_window, tw, a.eps, a.shift);                   \
-    } while (0)
+#define SDRK_LAUNCH(W, E)                                                                            \
+    hipLaunchKernelGGL((fft4096_kernel<W, E>), g, b, 0, a.stream, iq, a.frame_stride, a.d_out,           \
+                       a.n_frames, a.d_window, tw, a.eps, a.shift)
     if (a.epilogue == EPI_LOGPSD) {
-        if (a.fast_log) {
-            if (a.d_window) SDRK_LAUNCH(true, EPI_LOGPSD, true); else SDRK_LAUNCH(false, EPI_LOGPSD, true);
-        } else {
-            if (a.d_window) SDRK_LAUNCH(true, EPI_LOGPSD, false); else SDRK_LAUNCH(false, EPI_LOGPSD, false);
-        }
+        if (a.d_window) SDRK_LAUNCH(true, EPI_LOGPSD); else SDRK_LAUNCH(false, EPI_LOGPSD);
     } else {
-        if (a.d_window) SDRK_LAUNCH(true, EPI_COMPLEX, false); else SDRK_LAUNCH(false, EPI_COMPLEX, false);
+        if (a.d_window) SDRK_LAUNCH(true, EPI_COMPLEX); else SDRK_LAUNCH(false, EPI_COMPLEX);
     }
 #undef SDRK_LAUNCH
     return hipGetLastError();

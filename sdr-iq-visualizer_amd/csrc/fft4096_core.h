@@ -28,7 +28,6 @@ struct F4kAddr {
     int x1w_even, x1w_odd;  // exchange-1 write: (tid ^ 16*(k&1)) + 256 k
     int x1r_even, x1r_odd;  // exchange-1 read : lo + 16 (j ^ (hi&1)) + 256 hi
     int x2w;                // exchange-2 write: hi + 16 k + 257 lo ; read: tid + 257 j
-    cf w1_4096, w1_256;     // F4K_TWCHAIN: W4096^tid and W256^lo
 };
 
 __device__ __forceinline__ F4kAddr f4k_addr(int tid) {
@@ -48,23 +47,11 @@ __device__ __forceinline__ F4kAddr f4k_addr(int tid) {
 // Caller must __syncthreads() before the first f4k_transform().
 __device__ __forceinline__ void f4k_init_tables(float2* __restrict__ tw256, float2* __restrict__ tw4k,
                                                 const float2* __restrict__ tw4096, int tid, F4kAddr& A) {
-    {
-        float2 a = tw4096[tid], b = tw4096[16 * (tid & 15)];
-        A.w1_4096 = cf{a.x, a.y};
-        A.w1_256 = cf{b.x, b.y};
-    }
+    (void)A;
     const int lo = tid & 15, hi = tid >> 4;
     tw256[tid] = tw4096[(16 * lo * hi) & (F4K_N - 1)];  // [k=hi][n=lo] = W256^(lo hi)
     tw4k[tid] = tw4096[lo * hi];                         // [k=hi][n=lo] = W4096^(lo hi)
 }
-
-// Tuning switches (tools/kbench.hip builds variants; production uses the defaults).
-#ifndef F4K_TWCHAIN
-#define F4K_TWCHAIN 0   // 1: inter-pass twiddles w^k by a depth<=4 product tree from w^1 (no LDS tables)
-#endif
-#ifndef F4K_ABLATE
-#define F4K_ABLATE 0    // timing-only ablations (wrong results): 1 = no LDS exchange / barriers
-#endif
 
 // w[k] = w1^k for k = 1..15 with multiplication depth <= 4 (w2=w1^2, w4=w2^2, w8=w4^2).
 __device__ __forceinline__ void pow_tree(cf w1, cf (&w)[16]) {
@@ -88,31 +75,17 @@ __device__ __forceinline__ void pow_tree(cf w1, cf (&w)[16]) {
 // v[j] = x[tid + 256 j] on entry; on return X[tid + 256 k2] is in v[rev16(k2)].
 // Contains four workgroup barriers; the first one also protects the previous
 // call's exchange-2 reads, so calls may follow each other directly.
-template <bool TWCHAIN = (F4K_TWCHAIN != 0)>
 __device__ __forceinline__ void f4k_transform(cf (&v)[16], float2* __restrict__ lds,
                                               const float2* __restrict__ tw256,
                                               const float2* __restrict__ tw4k, const F4kAddr& A,
                                               int tid) {
     // ---- pass 1: DFT-16 over n2, times W4096^(r k0) = tw4k[k0][n0] * tw256[k0][n1] ----
     radix16(v);
-    if (TWCHAIN) {
-        cf w[16], w1 = A.w1_4096;
-        asm volatile("" : "+v"(w1.x), "+v"(w1.y));  // opaque: keep the tree inside the frame loop (no LICM into 30 VGPRs)
-        pow_tree(w1, w);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
-    } else {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            float2 wa = tw4k[16 * k + A.lo], wb = tw256[16 * k + A.hi];
-            v[rev16(k)] = cmul(v[rev16(k)], cmul(cf{wa.x, wa.y}, cf{wb.x, wb.y}));
-        }
+    for (int k = 1; k < 16; ++k) {
+        float2 wa = tw4k[16 * k + A.lo], wb = tw256[16 * k + A.hi];
+        v[rev16(k)] = cmul(v[rev16(k)], cmul(cf{wa.x, wa.y}, cf{wb.x, wb.y}));
     }
-#if F4K_ABLATE == 1
-    radix16(v);
-    radix16(v);
-    return;
-#endif
     __syncthreads();  // previous transform's pass-3 reads are done
 #pragma unroll
     for (int k = 0; k < 16; ++k)
@@ -125,18 +98,10 @@ __device__ __forceinline__ void f4k_transform(cf (&v)[16], float2* __restrict__ 
         v[j] = cf{t.x, t.y};
     }
     radix16(v);
-    if (TWCHAIN) {
-        cf w[16], w1 = A.w1_256;
-        asm volatile("" : "+v"(w1.x), "+v"(w1.y));
-        pow_tree(w1, w);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
-    } else {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            float2 w = tw256[16 * k + A.lo];
-            v[rev16(k)] = cmul(v[rev16(k)], cf{w.x, w.y});
-        }
+    for (int k = 1; k < 16; ++k) {
+        float2 w = tw256[16 * k + A.lo];
+        v[rev16(k)] = cmul(v[rev16(k)], cf{w.x, w.y});
     }
     __syncthreads();  // exchange-1 reads are done
 #pragma unroll

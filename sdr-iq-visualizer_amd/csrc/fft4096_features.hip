@@ -63,7 +63,7 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_features_kerne
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = v[j] * lds_win[tid + 256 * j];
         }
-        f4k_transform<false>(v, lds, tw256, tw4k, A, tid);
+        f4k_transform(v, lds, tw256, tw4k, A, tid);
         __syncthreads();   // every thread is through its last exchange read: the buffer becomes the row
         // bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor)
         __amdgpu_buffer_rsrc_t w = frame_rsrc(out_db ? out_db + f * (size_t)F4K_N : nullptr, out_db ? F4K_N * 4 : 0);

@@ -25,8 +25,6 @@ struct LaunchArgs {
     float eps = 1e-12f;
     int shift = 1;
     int epilogue = EPI_LOGPSD;
-    bool tw_chain = false;             // fft4096: inter-pass twiddles by product tree instead of LDS tables
-    bool fast_log = false;             // fft4096: skip sqrt/+eps where it cannot change the float32 result (A/B: 1.5 % slower; off)
     hipStream_t stream = nullptr;
     int num_cus = 256;
     void* d_scratch = nullptr;         // large-N plans: complex64 scratch, scratch_frames*nfft

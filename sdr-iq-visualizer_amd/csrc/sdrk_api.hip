@@ -487,10 +487,17 @@ int sdrk_dev_free(int device, void* d_ptr) {
     return SDRK_OK;
 }
 
-int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, int candidates, void** d_in,
-                               void** d_out, float* probe_ms, int* chosen) {
+int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, int candidates, sdrk_plan* plan,
+                               void** d_in, void** d_out, float* probe_ms, int* chosen) {
     if (!d_in || !d_out) return fail(SDRK_ERR_INVALID, "d_in or d_out is NULL");
     *d_in = *d_out = nullptr;
+    size_t plan_frames = 0;
+    if (plan) {
+        if (plan->device != device) return fail(SDRK_ERR_INVALID, "plan is on device %d, not %d", plan->device, device);
+        plan_frames = in_bytes / ((size_t)plan->nfft * sizeof(float2));
+        if (plan_frames == 0 || out_bytes < plan_frames * (size_t)plan->nfft * sizeof(float))
+            return fail(SDRK_ERR_INVALID, "buffers do not hold whole frames of the plan's length");
+    }
     if (chosen) *chosen = 0;
     if (candidates < 1) candidates = 1;
     if (candidates > 16) candidates = 16;
@@ -510,6 +517,7 @@ int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, in
         while (candidates > 1 && (size_t)candidates * out_bytes + ((size_t)1 << 30) > free_b) --candidates;
     }
     if (pf < ((size_t)1 << 13)) candidates = 1;
+    if (plan && plan_frames > ((size_t)1 << 32) / (size_t)plan->nfft) plan_frames = ((size_t)1 << 32) / (size_t)plan->nfft;
     std::vector<void*> cand((size_t)candidates, nullptr);
     std::vector<float> ms((size_t)candidates, 0.0f);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -533,7 +541,12 @@ int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, in
         float t[4];
         for (int r = 0; r < 4 && e == hipSuccess; ++r) {
             e = hipEventRecord(e0, s);
-            if (e == hipSuccess) e = sdrk::launch_stream_mix(*d_in, cand[(size_t)c], pf, prop.multiProcessorCount, s);
+            if (e == hipSuccess && plan) {            // the plan's own transform over the pair: what will really run
+                int pst = plan_launch(plan, *d_in, plan_frames, (size_t)plan->nfft, cand[(size_t)c], sdrk::EPI_LOGPSD, s);
+                if (pst != SDRK_OK) e = hipErrorUnknown;
+            } else if (e == hipSuccess) {
+                e = sdrk::launch_stream_mix(*d_in, cand[(size_t)c], pf, prop.multiProcessorCount, s);
+            }
             if (e == hipSuccess) e = hipEventRecord(e1, s);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
             if (e == hipSuccess) e = hipEventElapsedTime(&t[r], e0, e1);

@@ -72,14 +72,12 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     double bytes = 12.0 * nf * 4096;
     printf("d_in=%p d_out=%p\n", d_in, d_out);
-    printf("variant: WAVES=%d TWCHAIN=%d FASTLOG=%d NT=%d ABLATE=%d  frames=2^%d window=%d\n", F4K_WAVES, F4K_TWCHAIN, -1, F4K_NT, F4K_ABLATE, lg, win);
+    printf("variant: WAVES=%d NT=%d  frames=2^%d window=%d\n", F4K_WAVES, F4K_NT, lg, win);
     sdrk::LaunchArgs a; a.d_iq = d_in; a.frame_stride = 4096; a.d_out = d_out; a.n_frames = nf; a.nfft = 4096;
     a.d_window = win ? d_win : nullptr; a.d_twiddle = d_tw; a.stream = s; a.num_cus = prop.multiProcessorCount;
     for (int round = 0; round < 3; ++round) {   // interleaved A/B on the same buffers
-        a.fast_log = false; a.tw_chain = false;
-        time_it("fft4096 table twiddles", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
-        a.tw_chain = true;
-        time_it("fft4096 product-tree twiddles", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+        time_it("fft4096", reps, bytes, s, [&] { CK(sdrk::launch_fft4096(a)); });
+        time_it("no-arithmetic 2:1 stream (same buffers)", reps, bytes, s, [&] { CK(sdrk::launch_stream_mix(d_in, d_out, nf, prop.multiProcessorCount, s)); });
     }
     if (argc > 5) {   // single-slab experiment: input and output carved from ONE allocation at chosen offsets
         void* slab; const size_t in_b = nf * 4096 * 8, out_b = nf * 4096 * 4;

@@ -322,7 +322,7 @@ def test_stream_pair_allocation_probes_and_returns_usable_buffers(pkg):
     nf, n = 1 << 14, 4096
     d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
     ms, chosen = (ctypes.c_float * 3)(), ctypes.c_int(-1)
-    _ffi.check(lib.sdrk_dev_alloc_stream_pair(0, nf * n * 8, nf * n * 4, 3, ctypes.byref(d_in), ctypes.byref(d_out),
+    _ffi.check(lib.sdrk_dev_alloc_stream_pair(0, nf * n * 8, nf * n * 4, 3, None, ctypes.byref(d_in), ctypes.byref(d_out),
                                               ms, ctypes.byref(chosen)))
     try:
         assert d_in.value and d_out.value and 0 <= chosen.value < 3
@@ -339,10 +339,20 @@ def test_stream_pair_allocation_probes_and_returns_usable_buffers(pkg):
         lib.sdrk_dev_free(0, d_in)
         lib.sdrk_dev_free(0, d_out)
     small = (ctypes.c_float * 4)()
-    _ffi.check(lib.sdrk_dev_alloc_stream_pair(0, 64 * n * 8, 64 * n * 4, 4, ctypes.byref(d_in), ctypes.byref(d_out), small, None))
+    _ffi.check(lib.sdrk_dev_alloc_stream_pair(0, 64 * n * 8, 64 * n * 4, 4, None, ctypes.byref(d_in), ctypes.byref(d_out), small, None))
     assert d_in.value and d_out.value and list(small) == [0.0] * 4          # too small to matter: plain allocation
     lib.sdrk_dev_free(0, d_in)
     lib.sdrk_dev_free(0, d_out)
+    # probing with a plan's own transform (what bench.py does), here N = 65536 Hann
+    with SpectrumPlan(65536, window="hann") as plan:
+        ms2 = (ctypes.c_float * 2)()
+        _ffi.check(lib.sdrk_dev_alloc_stream_pair(0, 1024 * 65536 * 8, 1024 * 65536 * 4, 2, plan.handle, ctypes.byref(d_in),
+                                                  ctypes.byref(d_out), ms2, ctypes.byref(chosen)))
+        assert all(v > 0 for v in ms2) and chosen.value in (0, 1)
+        lib.sdrk_dev_free(0, d_in)
+        lib.sdrk_dev_free(0, d_out)
+        with pytest.raises(ValueError):
+            _ffi.check(lib.sdrk_dev_alloc_stream_pair(0, 1000, 1000, 2, plan.handle, ctypes.byref(d_in), ctypes.byref(d_out), None, None))
 
 
 def test_device_generator_bit_identical_to_numpy_mirror(pkg):
