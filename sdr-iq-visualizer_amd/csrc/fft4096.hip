@@ -41,7 +41,9 @@ namespace sdrk {
 // (Tried and dropped, A/B on the same buffers: twiddles by product tree instead of LDS tables (neutral), a sqrt-free
 // log epilogue (1.5 % slower), and sending the row through LDS once more so that it leaves as four 16-byte stores
 // per thread instead of sixteen 4-byte ones (1.0-1.5 % slower: two more barriers per frame cost more than the
-// narrower stores do).)
+// narrower stores do); issuing the prefetch through inline asm with an exact `s_waitcnt vmcnt(16)` in front of its first
+// use — hipcc waits vmcnt(0) there, i.e. also for the previous frame's stores — changed nothing either: with three
+// workgroups per CU another wave always has work while one waits for its store acknowledgements.)
 template <bool HAS_WINDOW, int EPILOGUE>
 __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     const float2* __restrict__ iq, size_t frame_stride, void* __restrict__ out_raw,
