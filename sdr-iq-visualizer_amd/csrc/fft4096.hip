@@ -79,29 +79,23 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     const size_t first = blockIdx.x;
     const size_t step = gridDim.x;
 
-    // Software pipeline prologue: loads of the first frame.
-    v2u nxt[16];
-    {
-        __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + first * frame_stride, F4K_N * 8);
+    // Software pipeline: each workgroup keeps the loads of its next frame in flight while it transforms the
+    // current one.  (Two frames ahead — 64 KiB per workgroup in flight — measured 2.5 % slower against the
+    // same-buffers copy: 1.055x instead of 1.030x its time.)
+    auto issue = [&](v2u (&x)[16], size_t fr) {
+        if (fr >= n_frames) fr = first;  // harmless re-read past the end
+        __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + fr * frame_stride, F4K_N * 8);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, F4K_NT);
-    }
-    for (size_t f = first; f < n_frames; f += step) {
+        for (int j = 0; j < 16; ++j) x[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, F4K_NT);
+    };
+    auto process = [&](v2u (&x)[16], size_t f) {
         cf v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            v2f t = __builtin_bit_cast(v2f, nxt[j]);
+            v2f t = __builtin_bit_cast(v2f, x[j]);
             v[j] = cf{t.x, t.y};
         }
-        {
-            size_t fn = f + step;
-            if (fn >= n_frames) fn = f;  // harmless re-read on the last trip
-            __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + fn * frame_stride, F4K_N * 8);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, F4K_NT);
-        }
+        issue(x, f + step);
         if (HAS_WINDOW) {
 #pragma unroll
 #if F4K_WINREG
@@ -131,7 +125,10 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
                                                       (k2 ^ xor_k2) * 2048, 0);
             }
         }
-    }
+    };
+    v2u nxt[16];
+    issue(nxt, first);
+    for (size_t f = first; f < n_frames; f += step) process(nxt, f);
 }
 
 hipError_t launch_fft4096(const LaunchArgs& a) {

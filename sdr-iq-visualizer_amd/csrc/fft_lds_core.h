@@ -76,13 +76,16 @@ __device__ __forceinline__ void lds_tw_init(LdsTw<LOG2N>& tw, const float2* __re
 // lds[a * IL + off]: IL = 1 with a per-frame base for frame-per-thread-group use, IL = 16 and
 // off = column for sixteen interleaved columns.  Contains 2 (P-1) workgroup barriers; the first
 // also protects the previous call's last reads.
+constexpr int LDS_HOOK_LAST_READS = -1;   // extra hook: the last pass has read its inputs, LDS is no longer needed
+
 struct NoHook {
     __device__ __forceinline__ void operator()(int) const {}
 };
 
 // `hook(k)` is called at lds_core_hooks<LOG2N, NV>() points spread over the transform, k counting up in call
 // order: after each set's first-pass butterflies, after each exchange has been written, after each set's
-// radix-16 of the later passes.  The tile loops use it to trickle the next tile's loads into the memory pipeline
+// radix-16 of the later passes — and once more with k = LDS_HOOK_LAST_READS when the last pass has issued its
+// LDS reads (from there on the transform works in registers only).  The tile loops use it to trickle the next tile's loads into the memory pipeline
 // instead of issuing them in one burst: a wave that issues 32 loads back to back sits in the issue stage until
 // the pipeline has taken them all, and with one workgroup per CU nothing else runs meanwhile (measured on the
 // M = 1024 row pass: 71.9 us per 24-frame chunk in one burst, 64.3 in two parts, 61.4 in four).
@@ -157,6 +160,7 @@ __device__ __forceinline__ void lds_fft_core_nv(cf (&v)[NV][16], float2* __restr
                 const float2 t = lds[(rr + Mq * j + Sin * Kin) * IL + off];
                 v[s][j] = cf{t.x, t.y};
             }
+            if (p == P - 1 && s == NV - 1) hook(LDS_HOOK_LAST_READS);
             radix16(v[s]);
             hook(NV + 1 + (p - 1) * (1 + NV) + s);
             if (p < P - 1) {

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     const float2* __restrict__ t2) {
     using C = LdsCfg<LOG2A>;
     constexpr int A = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0;
+    constexpr bool DMA_PREFETCH = !FIXED && W == 16 && T * W >= 512;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 17/16 A W elements: W interleaved columns
     const int tid = threadIdx.x;
     const int fr = tid & (W - 1), tau = tid / W;
@@ -153,6 +154,75 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
             store(f, m, v, bw);
 #pragma unroll
             for (int q = 0; q < 16; ++q) xa[q] = q < 16 - SH ? xa[q + SH] : xb[q];
+        }
+    } else if (DMA_PREFETCH) {
+        // Workgroups too large for a register prefetch (A >= 512: 512 / 1024 threads, 128 VGPRs): the NEXT tile's raw
+        // samples are fetched by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR destination) into the exchange
+        // area, which is free from the moment the last pass has read its inputs until the next tile's first
+        // exchange — i.e. during the last butterflies, the factor multiply and the 16 stores per thread.  A tile then
+        // starts by picking its samples up from LDS (row n3 of the tile = 128 contiguous bytes at n3 * 128) instead
+        // of waiting for 16 global loads per thread.  Measured at A = 1024 (24-frame chunks, Hann): 115 -> 108 us.
+        // It is a partial fix — the fetch can only start when the exchange area is free, i.e. for the last ~15 % of a
+        // tile; timing-only builds: transform alone 54 us, + fetch 77, + stores 76, all three 108 — because a
+        // 128 KiB tile leaves neither LDS nor registers (127 of 128 VGPRs at 1024 threads) for a second one.
+        // (staging layout: 16 columns = 128 bytes per row; DMA_PREFETCH is only true for W == 16)
+        constexpr int WAVES = T * W / 64, ROWS_PER_INSTR = 8;                 // 64 lanes x 16 B = 8 rows of 128 B
+        constexpr int INSTR = A / (ROWS_PER_INSTR * WAVES);                    // DMA instructions per wave and tile
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const __amdgpu_buffer_rsrc_t rw = frame_rsrc(window, HAS_WINDOW ? (unsigned)(nfft * 4) : 0u);
+        auto dma = [&](size_t g) {
+            if (g >= items) return;              // nothing may still be writing LDS when the workgroup exits
+            size_t f;
+            int m;
+            locate(g, f, m);
+            const int m0 = __builtin_amdgcn_readfirstlane(m - fr);            // first column of the tile
+            const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + f * frame_stride, (unsigned)(nfft * 8));
+            const int voff = ((lane >> 3) * M + m0) * 8 + (lane & 7) * 16;    // row lane/8 of the group, 16-byte piece lane%8
+#pragma unroll
+            for (int i = 0; i < INSTR; ++i) {
+                const int grp = wave + WAVES * i;                             // rows 8 grp .. 8 grp + 7
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rx, (__attribute__((address_space(3))) void*)(lds_all + grp * (ROWS_PER_INSTR * 16)), 16, voff,
+                    grp * ROWS_PER_INSTR * M * 8, 0, 2);
+            }
+        };
+        dma(blockIdx.x);
+        for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
+            size_t f;
+            int m;
+            locate(g, f, m);
+            const int e0 = tau * M + m;
+            float wv[16];
+            if (HAS_WINDOW) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    wv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, e0 * 4, q * estep * 4, 0));
+            }
+            __builtin_amdgcn_s_waitcnt(0);       // the staged samples (and the window values) have landed
+            __syncthreads();                     // ... in every wave
+            cf v[16];
+#pragma unroll
+            for (int i = 0; i < C0; ++i)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int q = i + C0 * j;
+                    const float2 t = lds_all[(tau + T * q) * 16 + fr];
+                    v[i * R0 + j] = HAS_WINDOW ? cf{t.x * wv[q], t.y * wv[q]} : cf{t.x, t.y};
+                }
+            cf bw[16];
+            lds_fft_core_nv<LOG2A, W, 1>(reinterpret_cast<cf (&)[1][16]>(v), lds_all, fr, tau,
+                                         reinterpret_cast<const LdsTw<LOG2A> (&)[1]>(tw), [&](int k) {
+                // the W_N^(m k3) factors are fetched while the last exchange is being written (the data registers
+                // are free then): these table loads are older than the DMA, so waiting for them later does not
+                // wait for it
+                if (k == lds_core_hooks<LOG2A, 1>() - 2) factors(m, bw);
+                if (k != LDS_HOOK_LAST_READS) return;
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's last-pass reads have returned
+                __builtin_amdgcn_s_barrier();    // ... and every other wave's: the exchange area is free (a raw barrier:
+                                                 // __syncthreads() would also wait for the table loads just issued)
+                dma(g + gridDim.x);
+            });
+            store(f, m, v, bw);
         }
     } else {
         const __amdgpu_buffer_rsrc_t rw = frame_rsrc(window, HAS_WINDOW ? (unsigned)(nfft * 4) : 0u);
@@ -261,7 +331,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS / NV, (NV > 1 ? 2 : (LdsCfg
 #pragma unroll
                 for (int j = 0; j < R0; ++j) v[s][i * R0 + j] = cf{xa[s][i + C0 * j].x, xa[s][i + C0 * j].y};
         lds_fft_core_nv<LOG2M, 1, NV>(v, lds, 0, rt, tw, [&](int k) {
-            if (PREFETCH) issue_part(nxt, xb, k + 1, NPARTS);
+            if (PREFETCH && k >= 0) issue_part(nxt, xb, k + 1, NPARTS);
         });
         __syncthreads();  // all rows are through their last LDS reads: the buffer becomes the transpose tile
         if (EPILOGUE == EPI_LOGPSD) {
