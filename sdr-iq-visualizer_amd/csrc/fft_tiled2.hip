@@ -54,7 +54,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     const float2* __restrict__ t2) {
     using C = LdsCfg<LOG2A>;
     constexpr int A = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0;
-    constexpr bool DMA_PREFETCH = !FIXED && W == 16 && T * W >= 512;
+    constexpr bool DMA_PREFETCH = !FIXED && W == 16 && T * W >= 512;   // A = 512 (two 512-thread workgroups per CU) and A = 1024 (one of 1024)
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 17/16 A W elements: W interleaved columns
     const int tid = threadIdx.x;
     const int fr = tid & (W - 1), tau = tid / W;
@@ -156,12 +156,13 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
             for (int q = 0; q < 16; ++q) xa[q] = q < 16 - SH ? xa[q + SH] : xb[q];
         }
     } else if (DMA_PREFETCH) {
-        // Workgroups too large for a register prefetch (A >= 512: 512 / 1024 threads, 128 VGPRs): the NEXT tile's raw
+        // Workgroups too large for a register prefetch (A >= 512: 512 / 1024 threads, <= 128 VGPRs): the NEXT tile's raw
         // samples are fetched by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR destination) into the exchange
         // area, which is free from the moment the last pass has read its inputs until the next tile's first
         // exchange — i.e. during the last butterflies, the factor multiply and the 16 stores per thread.  A tile then
         // starts by picking its samples up from LDS (row n3 of the tile = 128 contiguous bytes at n3 * 128) instead
-        // of waiting for 16 global loads per thread.  Measured at A = 1024 (24-frame chunks, Hann): 115 -> 108 us.
+        // of waiting for 16 global loads per thread.  Measured at A = 1024 (24-frame chunks, Hann): 115 -> 108 us
+        // (packed rect frames: N = 2^18 2.05 -> 2.12, 2^19 1.81 -> 1.92 TB/s algorithmic).
         // It is a partial fix — the fetch can only start when the exchange area is free, i.e. for the last ~15 % of a
         // tile; timing-only builds: transform alone 54 us, + fetch 77, + stores 76, all three 108 — because a
         // 128 KiB tile leaves neither LDS nor registers (127 of 128 VGPRs at 1024 threads) for a second one.
