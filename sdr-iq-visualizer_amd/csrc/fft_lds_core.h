@@ -78,6 +78,22 @@ __device__ __forceinline__ void lds_tw_init(LdsTw<LOG2N>& tw, const float2* __re
 // also protects the previous call's last reads.
 constexpr int LDS_HOOK_LAST_READS = -1;   // extra hook: the last pass has read its inputs, LDS is no longer needed
 
+// Workgroup barrier of the transform.  RAW = false: __syncthreads().  RAW = true: wait for this wave's own LDS
+// operations only, then s_barrier — for callers that keep an LDS-DMA (`buffer_load ... lds`) in flight across the
+// transform into a DIFFERENT part of LDS: __syncthreads() would make hipcc wait vmcnt(0) at every barrier and
+// drain it.  The empty asm statements keep the compiler from moving LDS accesses across the barrier.
+template <bool RAW>
+__device__ __forceinline__ void lds_core_barrier() {
+    if (RAW) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); vmcnt and expcnt untouched
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
+}
+
 struct NoHook {
     __device__ __forceinline__ void operator()(int) const {}
 };
@@ -93,7 +109,7 @@ template <int LOG2N, int NV>
 __host__ __device__ constexpr int lds_core_hooks() {
     return LdsCfg<LOG2N>::P > 1 ? NV + (LdsCfg<LOG2N>::P - 1) * (1 + NV) : NV;
 }
-template <int LOG2N, int IL, int NV, class Hook = NoHook>
+template <int LOG2N, int IL, int NV, class Hook = NoHook, bool RAW_BARRIER = false>
 __device__ __forceinline__ void lds_fft_core_nv(cf (&v)[NV][16], float2* __restrict__ lds, int off, int rt,
                                                 const LdsTw<LOG2N> (&tw)[NV], Hook&& hook = Hook()) {
     using C = LdsCfg<LOG2N>;
@@ -131,7 +147,7 @@ __device__ __forceinline__ void lds_fft_core_nv(cf (&v)[NV][16], float2* __restr
                 }
             }
         }
-        __syncthreads();  // previous transform's last-pass reads are done
+        lds_core_barrier<RAW_BARRIER>();  // previous transform's last-pass reads are done
         constexpr int S1 = C::Mp(0) + C::pad(1);
 #pragma unroll
         for (int s = 0; s < NV; ++s) {
@@ -145,7 +161,7 @@ __device__ __forceinline__ void lds_fft_core_nv(cf (&v)[NV][16], float2* __restr
                 }
         }
         hook(NV);
-        __syncthreads();
+        lds_core_barrier<RAW_BARRIER>();
     }
 #pragma unroll
     for (int p = 1; p < P; ++p) {
@@ -172,7 +188,7 @@ __device__ __forceinline__ void lds_fft_core_nv(cf (&v)[NV][16], float2* __restr
             }
         }
         if (p < P - 1) {
-            __syncthreads();  // everyone has read the layout entering pass p
+            lds_core_barrier<RAW_BARRIER>();  // everyone has read the layout entering pass p
             const int Sout = Mq + C::pad(p + 1);
             const int kstep = N / C::Np(p);
 #pragma unroll
@@ -186,7 +202,7 @@ __device__ __forceinline__ void lds_fft_core_nv(cf (&v)[NV][16], float2* __restr
                 }
             }
             hook(NV + 1 + (p - 1) * (1 + NV) + NV);
-            __syncthreads();
+            lds_core_barrier<RAW_BARRIER>();
         }
     }
 }

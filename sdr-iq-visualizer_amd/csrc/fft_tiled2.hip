@@ -54,7 +54,6 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     const float2* __restrict__ t2) {
     using C = LdsCfg<LOG2A>;
     constexpr int A = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0;
-    constexpr bool DMA_PREFETCH = !FIXED && W == 16 && T * W >= 512;   // A = 512 (two 512-thread workgroups per CU) and A = 1024 (one of 1024)
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 17/16 A W elements: W interleaved columns
     const int tid = threadIdx.x;
     const int fr = tid & (W - 1), tau = tid / W;
@@ -155,76 +154,6 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
 #pragma unroll
             for (int q = 0; q < 16; ++q) xa[q] = q < 16 - SH ? xa[q + SH] : xb[q];
         }
-    } else if (DMA_PREFETCH) {
-        // Workgroups too large for a register prefetch (A >= 512: 512 / 1024 threads, <= 128 VGPRs): the NEXT tile's raw
-        // samples are fetched by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR destination) into the exchange
-        // area, which is free from the moment the last pass has read its inputs until the next tile's first
-        // exchange — i.e. during the last butterflies, the factor multiply and the 16 stores per thread.  A tile then
-        // starts by picking its samples up from LDS (row n3 of the tile = 128 contiguous bytes at n3 * 128) instead
-        // of waiting for 16 global loads per thread.  Measured at A = 1024 (24-frame chunks, Hann): 115 -> 108 us
-        // (packed rect frames: N = 2^18 2.05 -> 2.12, 2^19 1.81 -> 1.92 TB/s algorithmic).
-        // It is a partial fix — the fetch can only start when the exchange area is free, i.e. for the last ~15 % of a
-        // tile; timing-only builds: transform alone 54 us, + fetch 77, + stores 76, all three 108 — because a
-        // 128 KiB tile leaves neither LDS nor registers (127 of 128 VGPRs at 1024 threads) for a second one.
-        // (staging layout: 16 columns = 128 bytes per row; DMA_PREFETCH is only true for W == 16)
-        constexpr int WAVES = T * W / 64, ROWS_PER_INSTR = 8;                 // 64 lanes x 16 B = 8 rows of 128 B
-        constexpr int INSTR = A / (ROWS_PER_INSTR * WAVES);                    // DMA instructions per wave and tile
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        const __amdgpu_buffer_rsrc_t rw = frame_rsrc(window, HAS_WINDOW ? (unsigned)(nfft * 4) : 0u);
-        auto dma = [&](size_t g) {
-            if (g >= items) return;              // nothing may still be writing LDS when the workgroup exits
-            size_t f;
-            int m;
-            locate(g, f, m);
-            const int m0 = __builtin_amdgcn_readfirstlane(m - fr);            // first column of the tile
-            const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + f * frame_stride, (unsigned)(nfft * 8));
-            const int voff = ((lane >> 3) * M + m0) * 8 + (lane & 7) * 16;    // row lane/8 of the group, 16-byte piece lane%8
-#pragma unroll
-            for (int i = 0; i < INSTR; ++i) {
-                const int grp = wave + WAVES * i;                             // rows 8 grp .. 8 grp + 7
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rx, (__attribute__((address_space(3))) void*)(lds_all + grp * (ROWS_PER_INSTR * 16)), 16, voff,
-                    grp * ROWS_PER_INSTR * M * 8, 0, 2);
-            }
-        };
-        dma(blockIdx.x);
-        for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
-            size_t f;
-            int m;
-            locate(g, f, m);
-            const int e0 = tau * M + m;
-            float wv[16];
-            if (HAS_WINDOW) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    wv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, e0 * 4, q * estep * 4, 0));
-            }
-            __builtin_amdgcn_s_waitcnt(0);       // the staged samples (and the window values) have landed
-            __syncthreads();                     // ... in every wave
-            cf v[16];
-#pragma unroll
-            for (int i = 0; i < C0; ++i)
-#pragma unroll
-                for (int j = 0; j < R0; ++j) {
-                    const int q = i + C0 * j;
-                    const float2 t = lds_all[(tau + T * q) * 16 + fr];
-                    v[i * R0 + j] = HAS_WINDOW ? cf{t.x * wv[q], t.y * wv[q]} : cf{t.x, t.y};
-                }
-            cf bw[16];
-            lds_fft_core_nv<LOG2A, W, 1>(reinterpret_cast<cf (&)[1][16]>(v), lds_all, fr, tau,
-                                         reinterpret_cast<const LdsTw<LOG2A> (&)[1]>(tw), [&](int k) {
-                // the W_N^(m k3) factors are fetched while the last exchange is being written (the data registers
-                // are free then): these table loads are older than the DMA, so waiting for them later does not
-                // wait for it
-                if (k == lds_core_hooks<LOG2A, 1>() - 2) factors(m, bw);
-                if (k != LDS_HOOK_LAST_READS) return;
-                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's last-pass reads have returned
-                __builtin_amdgcn_s_barrier();    // ... and every other wave's: the exchange area is free (a raw barrier:
-                                                 // __syncthreads() would also wait for the table loads just issued)
-                dma(g + gridDim.x);
-            });
-            store(f, m, v, bw);
-        }
     } else {
         const __amdgpu_buffer_rsrc_t rw = frame_rsrc(window, HAS_WINDOW ? (unsigned)(nfft * 4) : 0u);
         for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
@@ -256,13 +185,138 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     }
 }
 
-#ifndef SDRK_COL_W1024
-#define SDRK_COL_W1024 16   // 8 (two 512-thread workgroups per CU, 64-byte segments) measured 10 % slower at N = 2^20
-#endif
+// col pass with a staged fetch, for the sizes whose workgroups are too large for the register pipeline above:
+// A = 512 (N = 2^18, 2^19; W = 16 columns) and A = 1024 (N = 2^20, 2^21; W = 8).  A sixteen-column tile of A = 1024
+// is 128 KiB and leaves neither LDS nor registers for a second tile, so fetch, transform and store of the generic
+// kernel run one after the other; at A = 512 two such workgroups per CU overlap only by chance.  This kernel takes
+// 64 KiB of samples per tile and spends the other half of the LDS on a staging buffer for the NEXT tile's raw
+// samples, filled by LDS-DMA while the current tile is being transformed:
+//   LDS = [exchange area 17/16 x A x W complex | staging A rows x 8 W bytes]                  (133.5 KiB, 512 threads)
+//   per tile:  wait for the staged samples -> pick them up (x window) -> start the DMA of the next tile ->
+//              DFT-A in registers + exchange area (raw barriers: a __syncthreads() would drain the DMA) ->
+//              x W_N^(m k3) -> 16 stores per thread
+// A workgroup keeps one tile position for a run of consecutive frames (grid = a multiple of the M/W positions on a
+// full device), so its window coefficients and factors are registers for the whole run and the loop issues no
+// vector-memory instruction besides the DMA and the stores; the wait at the top of a tile is therefore an exact
+// vmcnt(16): the DMA is older than the previous tile's 16 stores, which may still be in flight.
+// The DMA is issued from inline assembly.  The compiler orders every LDS access that follows an LDS-DMA it knows
+// about behind a vmcnt(0) — also the accesses to the exchange area, which the DMA never writes — and that wait put
+// the whole fetch (and the previous tile's stores) back in front of the transform: at N = 2^20, 105.8 us per
+// 24-frame chunk with the builtin against 96.3 us like this (generic kernel: 107).  Timing-only builds there:
+// transform alone 34 us, + stores 49, + fetch 67, all three 96; FETCH_SIZE / WRITE_SIZE = 211 / 196 MB per chunk,
+// i.e. the algorithmic bytes: for W = 8 the two tiles that share each 128-byte line of input and of scratch go to
+// workgroups b and b + 8, the same XCD under the observed round-robin placement, so the second half of a line is
+// an L2 hit (a speed hint only; nothing depends on it).  With whole lines (A = 512, W = 16) the same structure
+// reaches 81.8 us per chunk of the same size at N = 2^18 (generic kernel: 94.0), 5.0 TB/s of streamed bytes.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // M0 is named as clobbered on purpose
+template <int LOG2A, bool HAS_WINDOW, int W>
+__global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kernel(
+    const float2* __restrict__ iq, size_t frame_stride, float2* __restrict__ scratch, size_t n_frames, int M,
+    const float* __restrict__ window, const float2* __restrict__ twA, const float2* __restrict__ t1T,
+    const float2* __restrict__ t2) {
+    using C = LdsCfg<LOG2A>;
+    constexpr int A = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0;
+    constexpr int LPR = W / 2;                                            // lanes per row: 16 bytes each
+    constexpr int WAVES = T * W / 64, ROWS_PER_INSTR = 64 / LPR;
+    constexpr int INSTR = A / (ROWS_PER_INSTR * WAVES);                  // DMA instructions per wave and tile
+    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
+    float2* __restrict__ xch = lds_all;                                   // SLOT * W elements
+    float2* __restrict__ stage = lds_all + C::SLOT * W;                   // A * W elements, row n3 at n3 * W
+    const int tid = threadIdx.x;
+    const int fr = tid & (W - 1), tau = tid / W;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    LdsTw<LOG2A> tw;
+    lds_tw_init<LOG2A>(tw, twA, tau);
+    const size_t nfft = (size_t)A * M;
+    const int tiles = M / W;
+    // work units: (tile position, run of frames); one per workgroup when the grid is a multiple of `tiles`
+    const size_t lanes = gridDim.x >= (unsigned)tiles ? gridDim.x / tiles : 1;
+    const size_t run = (n_frames + lanes - 1) / lanes;
+    typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+    for (size_t unit = blockIdx.x; unit < lanes * tiles; unit += gridDim.x) {
+        const int p = (int)(unit % tiles);
+        // W == 8: positions b and b + 8 share the 128-byte lines
+        const int t = (W == 8 && (tiles & 15) == 0) ? (p & ~15) + ((p & 7) << 1) + ((p >> 3) & 1) : p;
+        const int m0 = t * W, m = m0 + fr;
+        const size_t ln = unit / tiles;
+        const size_t f_begin = ln * run, f_end = f_begin + run < n_frames ? f_begin + run : n_frames;
+        if (f_begin >= f_end) continue;
+
+        float wreg[16];
+        if (HAS_WINDOW) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) wreg[q] = window[(size_t)(tau + T * q) * M + m];
+        }
+        cf bw[16];   // W_N^(m k3) for k3 = tau + T q
+        {
+            const float2 b0 = t1T[tau * M + m];
+            const cf base = cf{b0.x, b0.y};
+            const float4* __restrict__ row = reinterpret_cast<const float4*>(t2 + (size_t)m * 16);
+#pragma unroll
+            for (int q2 = 0; q2 < 8; ++q2) {
+                const float4 w = row[q2];
+                bw[2 * q2] = cmul(base, cf{w.x, w.y});
+                bw[2 * q2 + 1] = cmul(base, cf{w.z, w.w});
+            }
+        }
+        const int voff = ((lane / LPR) * M + m0) * 8 + (lane % LPR) * 16;   // row lane/LPR of the group, 16-byte piece lane%LPR
+        auto dma = [&](size_t f) {
+            if (f >= f_end) return;                  // nothing may still be writing LDS when the workgroup exits
+            const unsigned long long base = (unsigned long long)(iq + f * frame_stride);
+            const v4u32 rx = {(unsigned)base, (unsigned)(base >> 32) & 0xffffu, (unsigned)(nfft * 8), 0x00020000u};
+#pragma unroll
+            for (int i = 0; i < INSTR; ++i) {
+                const int grp = wave + WAVES * i;                          // rows ROWS_PER_INSTR * grp ...
+                const unsigned lds_addr =
+                    (unsigned)(size_t)(__attribute__((address_space(3))) void*)(stage + grp * (ROWS_PER_INSTR * W));
+                // M0 = LDS base of the wave's 1 KiB; one wait state between the M0 write and the LDS-DMA
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                             :: "s"(lds_addr), "v"(voff), "s"(rx), "s"(grp * ROWS_PER_INSTR * M * 8) : "memory", "m0");
+            }
+        };
+        if (unit != blockIdx.x) {                    // (partial devices only: more than one unit per workgroup)
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the table loads above must not be counted as stores
+            lds_core_barrier<true>();
+        }
+        dma(f_begin);
+        const int so = scratch_index(tau, m, M);
+        for (size_t f = f_begin; f < f_end; ++f) {
+            // the staged tile has landed: everything older than the previous tile's 16 stores is complete
+            if (f == f_begin) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x4F70);                       // vmcnt(16)
+            lds_core_barrier<true>();                                      // ... in every wave
+            cf v[16];
+#pragma unroll
+            for (int i = 0; i < C0; ++i)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int q = i + C0 * j;
+                    const float2 x = stage[(tau + T * q) * W + fr];
+                    v[i * R0 + j] = HAS_WINDOW ? cf{x.x * wreg[q], x.y * wreg[q]} : cf{x.x, x.y};
+                }
+            lds_core_barrier<true>();                                      // every wave has picked its samples up
+            dma(f + 1);
+            lds_fft_core_nv<LOG2A, W, 1, NoHook, true>(reinterpret_cast<cf (&)[1][16]>(v), xch, fr, tau,
+                                                       reinterpret_cast<const LdsTw<LOG2A> (&)[1]>(tw));
+            const __amdgpu_buffer_rsrc_t ro = frame_rsrc(scratch + f * nfft, (unsigned)(nfft * 8));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const cf z = cmul(v[rev16(q)], bw[q]);
+                const v2f sv = {z.x, z.y};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, scratch_index(T * q, 0, M) * 8, 0);
+            }
+        }
+    }
+}
+#pragma clang diagnostic pop
+
 #ifndef SDRK_COL_W256
 #define SDRK_COL_W256 16
 #endif
-#define COL_TILE_W(LOG2A) ((LOG2A) == 11 ? 8 : ((LOG2A) == 10 ? SDRK_COL_W1024 : ((LOG2A) == 8 ? SDRK_COL_W256 : 16)))
+// columns per col-pass tile; A = 1024 (and A = 512 when enabled) take col_pass_staged_kernel with STAGED_W columns
+#define STAGED_W(LOG2A) ((LOG2A) == 10 ? 8 : ((LOG2A) == 9 ? 16 : 0))
+#define COL_TILE_W(LOG2A) (STAGED_W(LOG2A) ? STAGED_W(LOG2A) : ((LOG2A) == 11 ? 8 : ((LOG2A) == 8 ? SDRK_COL_W256 : 16)))
 #define ROW_TILE_R(LOG2M) ((LOG2M) == 11 ? 8 : 16)
 
 // ROWS = rows per tile (16, or 8 for M = 2048 so that the tile fits the LDS).
@@ -393,8 +447,34 @@ bool fft_tiled2_split(int nfft, int* log2a, int* log2m) {
     return true;
 }
 
+// col pass through col_pass_staged_kernel: one 512-thread workgroup per CU (133.5 KiB of LDS)
+template <int LOG2A, int W>
+static hipError_t launch_col_staged(const LaunchArgs& a, const float2* src, size_t nf, int M) {
+    using C = LdsCfg<LOG2A>;
+    const unsigned tiles = (unsigned)(M / W);
+    unsigned grid = (unsigned)a.num_cus;
+    if (grid >= tiles) grid -= grid % tiles;             // whole runs of frames per tile position
+    const size_t lds_bytes = ((size_t)C::SLOT * W + (size_t)C::N * W) * sizeof(float2);
+    const float2* twA = static_cast<const float2*>(a.d_twiddle_2p);
+    const float2* t1T = twA + 2048 + 2048;
+    const float2* t2 = t1T + (size_t)(C::T) * M;
+    float2* scratch = static_cast<float2*>(a.d_scratch);
+#define SDRK_COLS(WIN)                                                                                           \
+    do {                                                                                                         \
+        auto kern = col_pass_staged_kernel<LOG2A, WIN, W>;                                                       \
+        static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                     \
+        hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
+        if (e0 != hipSuccess) return e0;                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * W), lds_bytes, a.stream, src, a.frame_stride, scratch, nf, M, \
+                           a.d_window, twA, t1T, t2);                                                            \
+    } while (0)
+    if (a.d_window) SDRK_COLS(true); else SDRK_COLS(false);
+#undef SDRK_COLS
+    return hipGetLastError();
+}
+
 template <int LOG2A>
-static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, int M, unsigned grid_cap) {
+static hipError_t launch_col_tiles(const LaunchArgs& a, const float2* src, size_t nf, int M, unsigned grid_cap) {
     using C = LdsCfg<LOG2A>;
     constexpr int W = COL_TILE_W(LOG2A);
     const size_t lds_bytes = (size_t)(C::SLOT) * W * sizeof(float2);
@@ -441,6 +521,12 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
     }
 #undef SDRK_COL
     return hipGetLastError();
+}
+
+template <int LOG2A>
+static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, int M, unsigned grid_cap) {
+    if constexpr (STAGED_W(LOG2A) != 0) return launch_col_staged<LOG2A, STAGED_W(LOG2A)>(a, src, nf, M);
+    else return launch_col_tiles<LOG2A>(a, src, nf, M, grid_cap);
 }
 
 #define ROW_NV(LOG2M) ((LOG2M) >= 10 ? 2 : 1)
@@ -495,7 +581,8 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
         auto gcd = [](size_t x, size_t y) { while (y) { size_t t = x % y; x = y; y = t; } return x; };
         const int Wc = COL_TILE_W(la <= 11 ? la : 11), Rr = ROW_TILE_R(lm <= 11 ? lm : 11);
         const bool pipelined = (A / 16) * Wc <= 256 && Wc >= 16;
-        size_t col_grid = Wc == 8 ? (size_t)a.num_cus * 2 : (pipelined ? (size_t)a.num_cus * 3 : cap(A < 1024 ? A : 1024));
+        size_t col_grid = STAGED_W(la) ? (size_t)a.num_cus
+                        : (Wc == 8 ? (size_t)a.num_cus * 2 : (pipelined ? (size_t)a.num_cus * 3 : cap(A < 1024 ? A : 1024)));
         if (pipelined && col_grid > cap(A)) col_grid = cap(A);
         const size_t row_grid = cap(M < 1024 ? M : 1024);
         size_t cw = col_grid / (size_t)(M / Wc), rw = row_grid / (size_t)(A / Rr);

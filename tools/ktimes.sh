@@ -12,7 +12,7 @@ for v in "$@"; do
 import csv,glob,sys
 for f in glob.glob("/tmp/kt_%s/*/*kernel_stats.csv" % sys.argv[1]):
     for r in csv.DictReader(open(f)):
-        if "pass_kernel" in r["Name"]:
+        if "_pass_" in r["Name"]:
             print(sys.argv[1], r["Name"][11:50], r["Calls"], "avg_us", round(float(r["AverageNs"])/1e3,2))
 PY
 done
