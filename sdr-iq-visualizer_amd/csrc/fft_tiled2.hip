@@ -19,15 +19,7 @@
 
 namespace sdrk {
 
-// Scratch layout between the passes.  The col pass produces, per workgroup, all A values of k3 for W adjacent
-// m; the row pass consumes 16 adjacent k3 for all M values of m: whatever the layout, the two footprints meet
-// in 16 x 16 element squares.  Stored as [k3/16][m/16][k3%16][m%16] (2 KiB squares, row tiles contiguous)
-// the col pass writes 2 KiB runs (512 B per wave instruction) instead of the 128-byte pieces at M*8-byte
-// stride a plain [k3][m] matrix costs it, and the row pass reads its 16 x M tile as one contiguous block.
-// element index of (k3, m) inside one frame's scratch
-__device__ __forceinline__ int scratch_index(int k3, int m, int M) {
-    return (((k3 >> 4) * (M >> 4) + (m >> 4)) << 8) + ((k3 & 15) << 4) + (m & 15);
-}
+// (scratch_index, the layout of the intermediate between the passes, lives in fft_lds_core.h)
 
 // W = tile width in columns (16, or 8 for A = 2048 so that the tile fits the LDS).
 // FIXED: the grid is a multiple of the tiles per frame, so every workgroup keeps the same tile position (same

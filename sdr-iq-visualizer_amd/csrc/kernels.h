@@ -29,7 +29,6 @@ struct LaunchArgs {
     int num_cus = 256;
     void* d_scratch = nullptr;         // large-N plans: complex64 scratch, scratch_frames*nfft
     size_t scratch_frames = 0;
-    const void* d_twiddle_fused = nullptr;  // fused N=65536 plans: W_N^(m k)[256][16] then W_N^(16 m q)[256][16]
     const void* d_twiddle_2p = nullptr;   // two-pass tiled plans: W_A[2048] W_M[2048] t1T[(A/16)*M] t2[M*16]
 };
 
@@ -78,9 +77,9 @@ hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frame
 
 // N = 65536 in one persistent launch, intermediate ring resident in each XCD's L2 (fft_fused64k.hip)
 size_t fused64k_ring_bytes();
-unsigned fused64k_max_slots(size_t n_frames, unsigned grid);
-size_t fused64k_ctrl_words_for(size_t n_frames, int num_cus);
-hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl, size_t ctrl_capacity_words);
+size_t fused64k_ctrl_words();
+unsigned fused64k_sets(int num_cus);      // sets of 32 workgroups a launch forms; ctrl[0] must equal it afterwards
+hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl);
 // arbitrary frame lengths (bluestein.hip)
 bool blu_fused_supports(int M);
 hipError_t launch_blu_fused(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,

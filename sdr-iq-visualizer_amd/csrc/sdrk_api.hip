@@ -94,7 +94,6 @@ struct sdrk_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float* d_window = nullptr;     // nfft floats, or nullptr for rectangular
     float2* d_twiddle = nullptr;   // W_min(nfft,4096)^m
-    float2* d_tw_fused = nullptr;  // fused N=65536 plans: the two [256][16] tables of fft_fused64k.hip
     float2* d_scratch = nullptr;   // large plans
     size_t scratch_frames = 0;
     void* d_in = nullptr;          // whole-stream staging (Welch PSD, waterfall append from host IQ); only grows
@@ -124,15 +123,13 @@ struct sdrk_plan {
     bool fused64k = false;
     void* d_fused_ring = nullptr;
     unsigned* d_fused_ctrl = nullptr;
-    size_t fused_ctrl_words = 0;
     unsigned* h_fused_err = nullptr;   // pinned mailbox: error word of the last launches
-    unsigned fused_launches = 0;
+    unsigned fused_launches = 0, fused_pending = 0;
 };
 constexpr size_t SMALL_IN_BYTES = 256 << 10;   // calls up to this much input take the zero-copy path
 constexpr size_t HOST_CHUNK_BYTES = 16 << 20;  // target input bytes per pipelined chunk of sdrk_exec_host
 constexpr size_t ZERO_COPY_MAX_BYTES = 32 << 20;  // calls up to this much input skip the DMA engines (see exec_host_common)
 constexpr unsigned FUSED_MAILBOX = 64;   // entries of 8 words: error flag + debug record
-constexpr size_t FUSED_PIECE = 1u << 16;  // frames per fused launch (sizes the control block once, at plan creation)
 
 struct sdrk_waterfall {
     int device = 0;
@@ -165,7 +162,6 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
     a.num_cus = p->num_cus;
     a.d_scratch = p->d_scratch;
     a.scratch_frames = p->scratch_frames;
-    a.d_twiddle_fused = p->d_tw_fused;
     a.d_twiddle_2p = p->d_tw_2p;
     hipError_t e = hipSuccess;
     if (p->blu_inner) {
@@ -201,18 +197,11 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
     else if (p->fused64k) {
-        // the control block was sized at plan creation for FUSED_PIECE frames; longer batches go through in pieces
-        e = hipSuccess;
-        for (size_t f0 = 0; f0 < n_frames && e == hipSuccess; f0 += FUSED_PIECE) {
-            sdrk::LaunchArgs b = a;
-            b.n_frames = n_frames - f0 < FUSED_PIECE ? n_frames - f0 : FUSED_PIECE;
-            b.d_iq = static_cast<const float2*>(d_iq) + f0 * frame_stride;
-            b.d_out = static_cast<char*>(d_out) + f0 * (size_t)p->nfft * (epilogue == sdrk::EPI_LOGPSD ? 4 : 8);
-            e = sdrk::launch_fused64k(b, p->d_fused_ring, p->d_fused_ctrl, p->fused_ctrl_words);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(p->h_fused_err + 16 * (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl + 1,
-                                   16 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
-        }
+        e = sdrk::launch_fused64k(a, p->d_fused_ring, p->d_fused_ctrl);
+        if (e == hipSuccess)   // error word, timeout record and the number of sets formed -> pinned mailbox
+            e = hipMemcpyAsync(p->h_fused_err + 16 * (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl,
+                               16 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+        ++p->fused_pending;
     } else if (p->tiled2)
         e = sdrk::launch_fft_tiled2(a);
     else
@@ -224,22 +213,19 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
 // After a stream sync: did any fused N=65536 launch report an internal wait timeout?
 int fused_check(sdrk_plan* p) {
     if (!p->fused64k || !p->h_fused_err) return SDRK_OK;
+    // mailbox entry: [0] sets formed + 1 (0 = unused entry), [1] error flag, [2..5] record of the first timeout
+    const unsigned want = sdrk::fused64k_sets(p->num_cus);
     unsigned bad = 0, rec[16] = {0};
-#ifdef FU_STATS
-    if (p->fused_launches) {
-        const unsigned* r = p->h_fused_err + 16 * ((p->fused_launches - 1) % FUSED_MAILBOX);
-        fprintf(stderr, "[fused64k stats] spins: cur-chunk %u prev-chunk %u | K1 ring wait %u spins in %u waits | "
-                "K3 done1 wait %u spins in %u waits\n", r[8], r[9], r[12], r[14], r[13], r[15]);
+    const unsigned pending = p->fused_pending < FUSED_MAILBOX ? p->fused_pending : FUSED_MAILBOX;
+    for (unsigned k = 0; k < pending; ++k) {            // the launches since the last check (older ones were overwritten)
+        const unsigned* r = p->h_fused_err + 16 * ((p->fused_launches - 1 - k) % FUSED_MAILBOX);
+        const unsigned code = r[1] ? r[1] : (r[0] != want ? 9u : 0u);
+        if (code) { memcpy(rec, r, sizeof rec); bad = code; }
     }
-#endif
-    for (unsigned i = 0; i < FUSED_MAILBOX; ++i) {
-        if (p->h_fused_err[16 * i] && !bad) memcpy(rec, p->h_fused_err + 16 * i, sizeof rec);
-        bad |= p->h_fused_err[16 * i];
-        memset(p->h_fused_err + 16 * i, 0, 16 * sizeof(unsigned));
-    }
+    p->fused_pending = 0;
     if (bad)
-        return fail(SDRK_ERR_HIP, "fused N=65536 kernel reported an internal synchronisation error (code %u; word %u held %u, "
-                    "wanted %u, site %u)", bad, rec[1], rec[2], rec[3], rec[4]);
+        return fail(SDRK_ERR_HIP, "fused N=65536 kernel reported an internal synchronisation error (code %u; %u of %u sets formed; "
+                    "word %u held %u, wanted %u, site %u)", bad, rec[0], want, rec[2], rec[3], rec[4], rec[5]);
     return SDRK_OK;
 }
 
@@ -739,24 +725,10 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
         p->tiled2 = true;
     }
     if (flags & SDRK_PLAN_FUSED64K) {
-        // Experimental single-launch, XCD-resident form of N = 65536 (fft_fused64k.hip).  Round-1 measurements:
-        // HBM traffic 14-21 B/sample instead of 28, but 1.4x slower than the two tiled launches (dependency
-        // stalls between the K1 and K3 tiles of a frame), so it is an explicit opt-in.
+        // Single-launch, XCD-resident form of N = 65536 (fft_fused64k.hip); shares the tables of the tiled path.
         p->fused64k = true;
-        std::vector<float2> t((size_t)2 * 256 * 16), w4096(4096);
-        for (int m = 0; m < 256; ++m)
-            for (int k = 0; k < 16; ++k) {
-                t[(size_t)m * 16 + k] = twiddle((double)m * k, 65536.0);
-                t[(size_t)256 * 16 + (size_t)m * 16 + k] = twiddle(16.0 * m * k, 65536.0);
-            }
-        for (int m = 0; m < 4096; ++m) w4096[m] = twiddle(m, 4096);
-        PLAN_TRY(hipMalloc((void**)&p->d_tw_fused, sizeof(float2) * t.size()));
-        PLAN_TRY(hipMemcpy(p->d_tw_fused, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
-        PLAN_TRY(hipMalloc((void**)&p->d_twiddle, sizeof(float2) * 4096));   // the kernel's in-LDS sub-transforms use W_4096
-        PLAN_TRY(hipMemcpy(p->d_twiddle, w4096.data(), sizeof(float2) * 4096, hipMemcpyHostToDevice));
         PLAN_TRY(hipMalloc(&p->d_fused_ring, sdrk::fused64k_ring_bytes()));
-        p->fused_ctrl_words = sdrk::fused64k_ctrl_words_for(FUSED_PIECE, p->num_cus);
-        PLAN_TRY(hipMalloc((void**)&p->d_fused_ctrl, p->fused_ctrl_words * sizeof(unsigned)));
+        PLAN_TRY(hipMalloc((void**)&p->d_fused_ctrl, sdrk::fused64k_ctrl_words() * sizeof(unsigned)));
         PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * 16 * sizeof(unsigned), hipHostMallocDefault));
         memset(p->h_fused_err, 0, FUSED_MAILBOX * 16 * sizeof(unsigned));
     }
@@ -771,7 +743,6 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->d_window) (void)hipFree(p->d_window);
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
-    if (p->d_tw_fused) (void)hipFree(p->d_tw_fused);
     if (p->d_tw_2p) (void)hipFree(p->d_tw_2p);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->blu_inner) (void)sdrk_plan_destroy(p->blu_inner);

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/collect_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 echo "== bench (full line)"; python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-echo "== profiles"; bash tools/profile_round.sh $TAG > "$OUT/profile_round.log" 2>&1; cp gpurun_out/prof_$TAG/summary.json "$OUT/rocprof_summary.json"
+echo "== profiles"; bash tools/profile_round.sh $TAG > "$OUT/profile_round.log" 2>&1; cp gpurun_out/prof_$TAG/summary.json "$OUT/rocprof_summary.json"; cp gpurun_out/prof_$TAG/pmc_fetch_write_rows.csv "$OUT/" 2>/dev/null
 for t in bench cfg3 cfg5; do cp gpurun_out/prof_$TAG/${t}_trace/*/*kernel_stats.csv "$OUT/${t}_kernel_stats.csv" 2>/dev/null; done
 echo "== size sweep"; python3 tools/size_sweep.py > "$OUT/size_sweep.log" 2>&1
 echo "== placement probes"
@@ -21,26 +21,12 @@ summ() { python3 -c "
 import json,sys
 l=json.loads(sys.stdin.read()); t=l['telemetry']
 print('%.4f  %.4f  %.4f  %.4f  %7.1f  %.4f  sclk_after %s  probe_ms %s chosen %d' % (l['launch_ms']['median'], l['launch_ms']['min'], l['launch_ms']['max'], l['roofline']['frac'], l['roofline']['measured_copy_GBps'], l['roofline']['frac_of_measured_copy'], t['after']['sclk_mhz'], l['placement']['probe_ms'], l['placement']['chosen']))"; }
-{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   (16 processes; placement: 4 candidates)";
+{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   (16 processes; placement: 6 candidates)";
   echo "# launch_ms median  min  max  frac_of_8TB/s  copy_GB/s  kernel/copy";
   for i in $(seq 16); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 2>/dev/null | tail -1 | summ; done; } > "$OUT/placement_16_runs.txt"
 { echo "# the same with --placement-candidates 1 (plain alloc(in); alloc(out)), 8 processes";
   for i in $(seq 8); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 --placement-candidates 1 2>/dev/null | tail -1 | summ; done; } > "$OUT/plain_alloc_8_runs.txt"
-echo "== fused vs tiled N=65536 (4096 packed frames, Hann)"
-python3 - > "$OUT/fused64k_vs_tiled.log" 2>&1 <<PY
-import ctypes, sys
-sys.path.insert(0, "$ROOT")
-from sdr_iq_visualizer_amd import _ffi
-from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
-lib = _ffi.lib(); n, nf = 65536, 4096
-d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
-_ffi.check(lib.sdrk_dev_alloc(0, nf * n * 8, ctypes.byref(d_in))); _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 4, ctypes.byref(d_out)))
-_ffi.check(lib.sdrk_synth_fill(0, 3, 0, nf * 16, 4096, d_in, None))
-for name, kw in (("two tiled launches", {}), ("fused (SDRK_PLAN_FUSED64K)", {"fused64k": True})):
-    with SpectrumPlan(n, window="hann", **kw) as p:
-        p.exec_device(d_in.value, nf, d_out.value); p.sync()
-        ms = sorted(p.exec_device_timed_each(d_in.value, nf, d_out.value, 7))
-        print(f"{name}: median {ms[3]:.3f} ms for {nf} packed frames of {n} ({12*nf*n/ms[3]/1e6:.0f} GB/s algorithmic)")
-PY
+echo "== fused vs tiled N=65536 (4096 packed frames, then config 3; Hann)"
+{ python3 tools/fused_probe.py 4096 65536 hann; python3 tools/fused_probe.py 18749 32768 hann; } > "$OUT/fused64k_vs_tiled.log" 2>&1
 cat "$OUT/fused64k_vs_tiled.log"; tail -3 "$OUT/placement_16_runs.txt"; tail -3 "$OUT/plain_alloc_8_runs.txt"
 echo "== gpu tests"; python3 -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -2 "$OUT/pytest_gpu.log"

@@ -26,4 +26,5 @@ for cfg in "cfg3 65536 18749 32768 hann" "cfg5 1048576 256 1048576 hann"; do
     run $1_write --pmc WRITE_SIZE --output-format csv -d "$OUT/$1_write" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5
 done
 python3 "$ROOT/tools/summarise_profiles.py" "$OUT" > "$OUT/summary.json" 2> "$OUT/summary.err"
+python3 "$ROOT/tools/summarise_profiles.py" "$OUT" --rows "$OUT/pmc_fetch_write_rows.csv" 2>> "$OUT/summary.err"
 cat "$OUT/summary.json"

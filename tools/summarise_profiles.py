@@ -13,9 +13,16 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
+def newest(dirname, pattern):
+    """The most recent file of one rocprofv3 output directory (gpurun merges every call's files into the same local
+    directories; on the GPU box there is only one)."""
+    files = glob.glob(os.path.join(dirname, "**", pattern), recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def stats(dirname):
     out = {}
-    for f in glob.glob(os.path.join(dirname, "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest(dirname, "*kernel_stats.csv"):
         for row in csv.DictReader(open(f)):
             out[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_us": round(float(row["AverageNs"]) / 1e3, 3),
                                        "min_us": round(float(row["MinNs"]) / 1e3, 3), "max_us": round(float(row["MaxNs"]) / 1e3, 3),
@@ -25,7 +32,7 @@ def stats(dirname):
 
 def pmc(dirname, counter):
     acc = defaultdict(list)
-    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(dirname, "*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
                 acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
@@ -51,5 +58,27 @@ def main(root):
     print(json.dumps(res, indent=1))
 
 
+def rows(root, out_csv):
+    """Every FETCH_SIZE / WRITE_SIZE row of the library's kernels from the six PMC passes, one CSV."""
+    cols = ["run", "Dispatch_Id", "Kernel", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name",
+            "Counter_Value_KB", "Start_ns", "End_ns"]
+    with open(out_csv, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(cols)
+        for tag in ("bench", "cfg3", "cfg5"):
+            for kind in ("fetch", "write"):
+                for f in newest(f"{root}/{tag}_{kind}", "*counter_collection.csv"):
+                    for r in csv.DictReader(open(f)):
+                        if "sdrk::" not in r["Kernel_Name"]:
+                            continue
+                        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+                        w.writerow([tag, r["Dispatch_Id"], name, r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"],
+                                    r["VGPR_Count"], r["Counter_Name"], r["Counter_Value"], r["Start_Timestamp"], r["End_Timestamp"]])
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r02")
+    root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r02"
+    if len(sys.argv) > 3 and sys.argv[2] == "--rows":
+        rows(root, sys.argv[3])
+    else:
+        main(root)
