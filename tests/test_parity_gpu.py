@@ -99,7 +99,7 @@ def test_empty_batch(pkg):
 
 
 @pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768,
-                               65536, 1 << 17, 1 << 18])
+                               65536, 1 << 17, 1 << 18, 1 << 19, 1 << 21])
 def test_every_power_of_two_vs_oracle(pkg, n):
     rng = np.random.default_rng(n)
     b = 5 if n <= 65536 else 2
@@ -226,6 +226,51 @@ def test_stft_large_frames_register_reuse_of_overlapped_samples(pkg, n, hop_div,
                                                ctypes.c_void_p(d_out.value + r * n * 4), n * 4))
             frames = np.stack([stream[r * hop: r * hop + n] for r in picks])
             assert_db_parity(got, cpu_ref.spectrum_db(frames, window=np.hanning(n)), what=f"N={n} hop=N/{hop_div}")
+        finally:
+            lib.sdrk_dev_free(0, d_out)
+    finally:
+        lib.sdrk_dev_free(0, d_in)
+
+
+@pytest.mark.parametrize("n,hop,rows,window,skew", [
+    (1 << 18, 1 << 18, 13, "hann", 0),            # A = 512: 16-column staged tiles; 13 frames = uneven runs per tile position
+    (1 << 18, (1 << 17) + 1, 9, None, 0),         # odd hop: frames start on 8-byte, not 16-byte, boundaries
+    (1 << 19, 1 << 19, 5, None, 1),               # input pointer itself only 8-byte aligned
+    (1 << 19, 3 << 17, 6, "hann", 0),
+    (1 << 20, 1 << 20, 27, "hann", 0),            # A = 1024: 8-column staged tiles; 27 frames = one 24-frame chunk + 3
+    (1 << 20, (1 << 19) - 3, 4, None, 3),
+    (1 << 21, 1 << 21, 3, "hann", 0),             # M = 2048: one run per tile position
+    (1 << 21, 1 << 20, 1, None, 0),
+])
+def test_staged_col_pass_runs_hops_and_alignment(pkg, n, hop, rows, window, skew):
+    """The col pass of N = 2^18 ... 2^21 fetches the next tile by LDS-DMA, 16 bytes per lane
+    (fft_tiled2.hip: col_pass_staged_kernel): frame counts that split unevenly over the workgroups of a
+    tile position, hops and base pointers that are not multiples of 16 bytes, both window kinds.
+    Device-resident stream; first, last and chunk-boundary rows against the oracle."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, synth
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    L = skew + n + (rows - 1) * hop
+    gen = (L + 4095) // 4096
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, gen * 4096 * 8, ctypes.byref(d_in)))
+    try:
+        _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_out)))
+        try:
+            _ffi.check(lib.sdrk_synth_fill(0, 909, 0, gen, 4096, d_in, None))
+            with SpectrumPlan(n, window=window) as plan:
+                plan.exec_device(d_in.value + skew * 8, rows, d_out.value, frame_stride=hop)
+                plan.sync()
+            stream = synth.synth_iq(909, 0, gen, 4096).reshape(-1)[skew:]
+            picks = sorted({0, 1, rows // 2, 23, 24, rows - 2, rows - 1} & set(range(rows)))
+            got = np.empty((len(picks), n), dtype=np.float32)
+            for i, r in enumerate(picks):
+                _ffi.check(lib.sdrk_memcpy_d2h(0, got[i].ctypes.data_as(ctypes.c_void_p),
+                                               ctypes.c_void_p(d_out.value + r * n * 4), n * 4))
+            frames = np.stack([stream[r * hop: r * hop + n] for r in picks])
+            ref = cpu_ref.spectrum_db(frames, window=np.hanning(n) if window == "hann" else None)
+            assert_db_parity(got, ref, what=f"N={n} hop={hop} rows={rows} skew={skew}")
         finally:
             lib.sdrk_dev_free(0, d_out)
     finally:
