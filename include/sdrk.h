@@ -74,6 +74,8 @@ int sdrk_device_info(int device, char* buf, size_t buf_len);
 
 int sdrk_dev_alloc(int device, size_t bytes, void** d_ptr);
 int sdrk_dev_free(int device, void* d_ptr);
+/* Free and total device memory in bytes (what the runtime reports for `device` right now). */
+int sdrk_dev_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 /* A long-lived input/output pair for the device-resident path, with the output placed where the two streams
  * interfere least.  On MI355X the achieved rate of a kernel that streams one buffer in and another out (the
  * spectrum path: 8 B in, 4 B out per sample) has two or three discrete levels ~6 % apart that depend on WHICH

@@ -52,6 +52,7 @@ SYMBOLS = [
     ("sdrk_last_error", c_char_p, []),
     ("sdrk_device_count", c_int, []),
     ("sdrk_device_info", c_int, [c_int, c_char_p, c_size_t]),
+    ("sdrk_dev_mem_info", c_int, [c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     ("sdrk_dev_alloc", c_int, [c_int, c_size_t, POINTER(c_void_p)]),
     ("sdrk_dev_free", c_int, [c_int, c_void_p]),
     ("sdrk_dev_alloc_stream_pair", c_int, [c_int, c_size_t, c_size_t, c_int, c_void_p, POINTER(c_void_p),

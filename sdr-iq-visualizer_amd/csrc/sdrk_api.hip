@@ -464,6 +464,15 @@ int sdrk_dev_alloc(int device, size_t bytes, void** d_ptr) {
     return SDRK_OK;
 }
 
+int sdrk_dev_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(SDRK_ERR_INVALID, "free_bytes / total_bytes is NULL");
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return SDRK_OK;
+}
+
 int sdrk_dev_free(int device, void* d_ptr) {
     if (!d_ptr) return SDRK_OK;
     int st = check_device(device);

@@ -905,3 +905,43 @@ def test_one_process_per_gpu_path_under_torchrun(pkg, tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- resources --------------------------------------------------------------------------
+
+def test_plans_waterfalls_and_feature_calls_release_their_device_memory(pkg):
+    """Create / use / destroy every kind of object the library allocates for, many times; the device's free
+    memory must come back (a leaked 192 MiB scratch or 64 MiB ring per plan would show within a few rounds)."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, features
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    rng = np.random.default_rng(77)
+    small = {n: rand_c64(rng, 2, n) for n in (4096, 1000, 8192, 65536)}
+    big = rand_c64(rng, 1, 1 << 20)
+
+    def one_round():
+        for n, x in small.items():
+            with SpectrumPlan(n, window="hann") as p:
+                p.spectrum_db(x)
+        with SpectrumPlan(65536, fused64k=True) as p:
+            p.spectrum_db(small[65536])
+        with SpectrumPlan(1 << 20) as p:
+            p.spectrum_db(big)
+        wf = pkg.WaterfallBuffer(4096, maxlen=100)
+        wf.append(small[4096][0])
+        wf.as_array()
+        wf.close()
+        features.frame_features(small[4096], 1e6, 2.4e9)
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        _ffi.check(_ffi.lib().sdrk_dev_mem_info(0, ctypes.byref(free), ctypes.byref(total)))
+        return free.value
+
+    for _ in range(3):                                  # library-wide pools (host staging, row scratch) and the
+        one_round()                                     # runtime's own one-time growth settle within the first rounds
+    free0 = free_bytes()
+    for _ in range(8):
+        one_round()
+    free1 = free_bytes()
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 8 rounds"

@@ -1,0 +1,35 @@
+"""Developer helper (GPU box): device memory before/after repeated create-use-destroy cycles, per object kind."""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import sdr_iq_visualizer_amd as pkg
+from sdr_iq_visualizer_amd import _ffi, features
+from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+
+def free_bytes():
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    _ffi.check(_ffi.lib().sdrk_dev_mem_info(0, ctypes.byref(free), ctypes.byref(total)))
+    return free.value
+
+rng = np.random.default_rng(1)
+def r(*s): return (rng.standard_normal(s) + 1j * rng.standard_normal(s)).astype(np.complex64)
+x = {n: r(2, n) for n in (4096, 1000, 8192, 65536)}
+big = r(1, 1 << 20)
+def plan(n, **kw):
+    def f():
+        with SpectrumPlan(n, **kw) as p:
+            p.spectrum_db(x.get(n, big))
+    return f
+def wf():
+    w = pkg.WaterfallBuffer(4096, maxlen=100); w.append(x[4096][0]); w.as_array(); w.close()
+kinds = {"plan4096": plan(4096, window="hann"), "plan1000": plan(1000), "plan8192": plan(8192), "plan65536": plan(65536, window="hann"),
+         "fused": plan(65536, fused64k=True), "plan2^20": plan(1 << 20), "waterfall": wf,
+         "features": lambda: features.frame_features(x[4096], 1e6, 2.4e9)}
+for name, f in kinds.items():
+    f()
+    a = free_bytes()
+    for _ in range(16): f()
+    b = free_bytes()
+    for _ in range(16): f()
+    c = free_bytes()
+    print(f"{name:10s} after 16: {(a-b)/2**20:8.2f} MiB  after 32: {(a-c)/2**20:8.2f} MiB")
