@@ -85,9 +85,10 @@ __device__ __forceinline__ bool wave_wait_all(const unsigned* words, unsigned wa
     return true;
 }
 
-// Workgroup-wide form: wave 0 polls, everybody learns the outcome through LDS (two barriers).  With every wave
-// polling on its own the kernel is 1.6x slower (3.6 instead of 2.2 ms per 4096 frames): agent-scope loads are
-// served behind the L2, and a few hundred waves re-reading the same lines get in the way of the data.
+// Workgroup-wide form: wave 0 polls, everybody learns the outcome through LDS (two barriers).  Measured per 4096
+// frames: every wave polling on its own 3.6 / 3.2 / 2.8 ms with s_sleep 1 / 16 / 64 between polls, wave 0 only
+// (s_sleep 4) 2.2 ms: agent-scope loads are served behind the L2, and hundreds of waves re-reading the same
+// lines compete with the data.
 __device__ __forceinline__ bool wg_wait_all(const unsigned* words, unsigned want, unsigned* ctrl, unsigned site, unsigned* sh) {
     if (threadIdx.x < 64) {
         const bool ok = wave_wait_all(words, want, ctrl, site);
