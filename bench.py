@@ -279,6 +279,44 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
             "GBps": round(algo / t / 1e9, 1), "frac": round(algo / t / 1e9 / HBM_PEAK_GBPS, 4)}
 
 
+def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=16, px=4096):
+    """BASELINE.json configs[4] as SURVEY.md §8(d) words it, one channel on this GPU: back-to-back N = 2^20 Hann
+    frames from a device-resident stream, every row appended to the device waterfall ring (100 x 4 MiB), and after
+    each batch of rows a decimated (max-hold to `px` bins) read-out of the new rows to the host."""
+    nfft = 1 << 20
+    d_in = ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(dev, n_frames * nfft * 8, ctypes.byref(d_in)))
+    wf = pkg.WaterfallBuffer(nfft, maxlen=100, device=dev)
+    try:
+        _ffi.check(lib.sdrk_synth_fill(dev, 1234 + dev, 0, n_frames * nfft // 4096, 4096, d_in, None))
+        with SpectrumPlan(nfft, window="hann", device=dev) as plan:
+            def run():
+                wf.clear()
+                got = 0
+                for f0 in range(0, n_frames, batch):
+                    _ffi.check(lib.sdrk_waterfall_append_iq_device(wf._h(), plan.handle,
+                                                                  ctypes.c_void_p(d_in.value + f0 * nfft * 8),
+                                                                  ctypes.c_size_t(batch), ctypes.c_size_t(nfft)))
+                    got += wf.as_array(max_rows=batch, decimate=nfft // px).shape[0]
+                return got
+            run()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                rows = run()
+                ts.append(time.perf_counter() - t0)
+    finally:
+        wf.close()
+        lib.sdrk_dev_free(dev, d_in)
+    t = _median(ts)
+    rate = n_frames * nfft / t / 1e6
+    return {"nfft": nfft, "frames": n_frames, "window": "hann", "ring_rows": 100, "gather": f"every {batch} rows, max-hold to {px} bins, D2H",
+            "rows_gathered": rows, "ms": round(t * 1e3, 3), "ms_min": round(min(ts) * 1e3, 3), "ms_max": round(max(ts) * 1e3, 3),
+            "Msamples_per_s": round(rate, 1), "realtime_factor_at_61.44_Msps": round(rate / 61.44, 1),
+            "realtime_61.44_Msps_holds": bool(rate >= 61.44),
+            "what": "transform -> device waterfall ring -> decimated host gather, host-timed (perf_counter) including every sync"}
+
+
 def numpy_boundary(lib, _ffi, pkg, synth, dev):
     """spectrum_db(host array) -> host array, PCIe and staging inclusive (never `value`)."""
     import numpy as np
@@ -518,6 +556,7 @@ def main():
             r["workload"] = "BASELINE.json configs[4], one channel: 256 back-to-back N=2^20 frames"
             r["realtime_factor_at_61.44_Msps"] = round((256 * (1 << 20) / 61.44e6) / (r["ms"] * 1e-3), 1)
             secondary["config5_one_channel"] = r
+            secondary["config5_channel_with_ring_and_gather"] = channel_config5(lib, _ffi, pkg, SpectrumPlan, dev)
             secondary["numpy_boundary"] = numpy_boundary(lib, _ffi, pkg, synth, dev)
             from sdr_iq_visualizer_amd import features
             secondary["row_features"] = feature_reductions(lib, _ffi, SpectrumPlan, features, dev)
