@@ -538,13 +538,31 @@ def main():
             copy_gbps = None
             print(f"[bench] stream ceiling probe failed: {e}", file=sys.stderr)
 
+    # the other window of configs[1] on the same buffers (SURVEY.md §8d names Hann and rect); rank 0, N = 1 only
+    other_window = None
+    if solo and not args.no_secondary:
+        try:
+            ow = None if args.window != "rect" else "hann"
+            with SpectrumPlan(NFFT, window=ow, device=dev) as p2:
+                p2.exec_device(d_in.value, frames, d_out.value)
+                p2.sync()
+                ms2 = p2.exec_device_timed_each(d_in.value, frames, d_out.value, launches=7)
+            t2 = _median(ms2) * 1e-3
+            other_window = {"window": ow or "rect", "frames": frames, "ms": round(t2 * 1e3, 4), "ms_min": round(min(ms2), 4),
+                            "ms_max": round(max(ms2), 4), "Msamples_per_s": round(frames * NFFT / t2 / 1e6, 1),
+                            "GBps": round(ALGO_BYTES_PER_SAMPLE * frames * NFFT / t2 / 1e9, 1),
+                            "frac": round(ALGO_BYTES_PER_SAMPLE * frames * NFFT / t2 / 1e9 / HBM_PEAK_GBPS, 4),
+                            "what": "same resident buffers as the timed run, median of 7 launches (HIP events)"}
+        except Exception as e:
+            other_window = {"error": f"{type(e).__name__}: {e}"}
+
     plan.close()
     lib.sdrk_dev_free(dev, d_in)
     lib.sdrk_dev_free(dev, d_out)
 
     secondary = None
     if solo and not args.no_secondary:
-        secondary = {}
+        secondary = {"config2_other_window": other_window}
         try:
             L = 614_400_000                                       # 10 s @ 61.44 Msps
             r = device_config(lib, _ffi, SpectrumPlan, dev, 65536, 1 + (L - 65536) // 32768, 32768, "hann", 7)
