@@ -251,8 +251,9 @@ def _median(v):
     return float(statistics.median(v))
 
 
-def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, reps):
-    """A device-resident run of one large-frame configuration: median launch time over `reps`."""
+def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, reps, scratch_candidates=6):
+    """A device-resident run of one large-frame configuration: median launch time over `reps`, after the plan's
+    scratch has been placed on this workload (sdrk_plan_tune_scratch; the probe times are reported)."""
     in_samples = (n_frames - 1) * stride + nfft
     gen_frames = (in_samples + 4095) // 4096
     d_gen, d_out = ctypes.c_void_p(), ctypes.c_void_p()
@@ -264,6 +265,7 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
             with SpectrumPlan(nfft, window=window, device=dev) as plan:
                 plan.exec_device(d_gen.value, n_frames, d_out.value, frame_stride=stride)
                 plan.sync()
+                probe, chosen = plan.tune_scratch(d_gen.value, n_frames, d_out.value, scratch_candidates, frame_stride=stride)
                 ms = plan.exec_device_timed_each(d_gen.value, n_frames, d_out.value, reps, frame_stride=stride)
         finally:
             lib.sdrk_dev_free(dev, d_out)
@@ -276,7 +278,10 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
             "input_Msamples_per_s": round(in_samples / t / 1e6, 1),
             "frame_Msamples_per_s": round(n_frames * nfft / t / 1e6, 1),
             "algorithmic_bytes": algo, "algorithmic_formula": "8*L + 4*rows*N",
-            "GBps": round(algo / t / 1e9, 1), "frac": round(algo / t / 1e9 / HBM_PEAK_GBPS, 4)}
+            "GBps": round(algo / t / 1e9, 1), "frac": round(algo / t / 1e9 / HBM_PEAK_GBPS, 4),
+            "scratch_placement": {"probe_ms": [round(v, 3) for v in probe], "chosen": chosen,
+                                  "what": "sdrk_plan_tune_scratch: the plan's transform timed with its own and five freshly "
+                                          "allocated scratch buffers, fastest kept (index 0 = untuned)"}}
 
 
 def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=16, px=4096):

@@ -113,6 +113,16 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind,
 #define SDRK_PLAN_FUSED64K 0x1u
 int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
                         const float* window, float eps, int shift, unsigned flags, sdrk_plan** out);
+/* Large-frame plans (nfft >= 2^15) keep their two-pass intermediate in a scratch buffer, and — like the resident
+ * input / output pair, see sdrk_dev_alloc_stream_pair — their speed depends a few per cent on WHERE that buffer
+ * landed relative to the data (N = 65536 STFT over the same buffers with six different scratch allocations:
+ * 5.02 ... 5.34 ms, stable per allocation).  This call times the plan's own transform of (d_iq, n_frames,
+ * frame_stride) -> d_out_db with the present scratch and with up to `candidates` - 1 freshly allocated ones,
+ * keeps the fastest and frees the others.  probe_ms (or NULL) receives `candidates` times (0 = not tried);
+ * chosen (or NULL) the index kept (0 = the original).  d_out_db is overwritten with the transform's result.
+ * Plans without a scratch return at once.  Not to be called while the plan is in use by another thread. */
+int sdrk_plan_tune_scratch(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames, size_t frame_stride_samples,
+                           float* d_out_db, int candidates, float* probe_ms, int* chosen);
 int sdrk_plan_destroy(sdrk_plan* plan);
 int sdrk_plan_nfft(const sdrk_plan* plan);
 int sdrk_plan_device(const sdrk_plan* plan);

@@ -63,6 +63,8 @@ SYMBOLS = [
      [c_int, c_int, c_size_t, c_int, c_void_p, c_float, c_int, POINTER(c_void_p)]),
     ("sdrk_plan_create_ex", c_int,
      [c_int, c_int, c_size_t, c_int, c_void_p, c_float, c_int, c_uint32, POINTER(c_void_p)]),
+    ("sdrk_plan_tune_scratch", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float),
+                                       POINTER(c_int)]),
     ("sdrk_plan_destroy", c_int, [c_void_p]),
     ("sdrk_plan_nfft", c_int, [c_void_p]),
     ("sdrk_plan_device", c_int, [c_void_p]),

@@ -893,6 +893,68 @@ int sdrk_exec_device_timed_each(sdrk_plan* p, const void* d_iq, size_t n_frames,
     return fused_check(p);
 }
 
+int sdrk_plan_tune_scratch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, float* d_out_db,
+                           int candidates, float* probe_ms, int* chosen) {
+    if (chosen) *chosen = 0;
+    int st = check_exec_args(p, d_iq, n_frames, frame_stride, d_out_db);
+    if (st != SDRK_OK) return st;
+    if (!p->d_scratch || p->scratch_frames == 0 || n_frames == 0) {      // no scratch (one-pass lengths): nothing to place
+        if (probe_ms) for (int c = 0; c < candidates; ++c) probe_ms[c] = 0.0f;
+        return SDRK_OK;
+    }
+    if (candidates < 2) return SDRK_OK;
+    if (candidates > 16) candidates = 16;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    const size_t bytes = p->scratch_frames * (size_t)p->nfft * sizeof(float2);
+    std::vector<float2*> cand((size_t)candidates, nullptr);
+    std::vector<float> ms((size_t)candidates, 0.0f);
+    cand[0] = p->d_scratch;                                               // candidate 0 = the plan's present scratch
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    int n_ok = 0;
+    for (int c = 0; c < candidates && e == hipSuccess; ++c) {
+        // earlier candidates stay allocated, so each new one lands somewhere else
+        if (c > 0 && hipMalloc((void**)&cand[(size_t)c], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            cand[(size_t)c] = nullptr;
+            break;
+        }
+        ++n_ok;
+        p->d_scratch = cand[(size_t)c];
+        float t[4];
+        for (int r = 0; r < 4 && e == hipSuccess; ++r) {
+            e = hipEventRecord(e0, p->stream);
+            if (e == hipSuccess && plan_launch(p, d_iq, n_frames, frame_stride, d_out_db, sdrk::EPI_LOGPSD, p->stream) != SDRK_OK)
+                e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipEventRecord(e1, p->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&t[r], e0, e1);
+        }
+        if (e == hipSuccess) {
+            std::sort(t + 1, t + 4);       // one warm-up, median of three
+            ms[(size_t)c] = t[2];
+        }
+    }
+    (void)hipStreamSynchronize(p->stream);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    int best = 0;
+    if (e == hipSuccess)
+        for (int c = 1; c < n_ok; ++c)
+            if (ms[(size_t)c] < ms[(size_t)best]) best = c;
+    p->d_scratch = cand[(size_t)best];
+    for (int c = 0; c < n_ok; ++c) {
+        if (probe_ms) probe_ms[c] = ms[(size_t)c];
+        if (c != best) (void)hipFree(cand[(size_t)c]);
+    }
+    if (probe_ms) for (int c = n_ok; c < candidates; ++c) probe_ms[c] = 0.0f;
+    if (chosen) *chosen = best;
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "scratch placement probe failed: %s", hipGetErrorString(e));
+    return fused_check(p);
+}
+
 int sdrk_stream_ceiling_probe(int device, const void* d_in, void* d_out, size_t n_frames4096, int launches,
                               float* each_ms) {
     if (!d_in || !d_out || !each_ms || launches < 1 || launches > 4096 || n_frames4096 == 0)

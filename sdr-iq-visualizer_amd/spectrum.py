@@ -28,7 +28,7 @@ from typing import Optional, Sequence, Union
 import numpy as np
 
 from . import _ffi
-from ._ffi import byref, c_float, c_size_t, c_void_p, check, lib
+from ._ffi import byref, c_float, c_int, c_size_t, c_void_p, check, lib
 
 WindowArg = Union[None, str, np.ndarray, Sequence[float]]
 
@@ -207,6 +207,17 @@ class SpectrumPlan:
         with self._lock:
             check(lib().sdrk_exec_device(self.handle, c_void_p(d_iq), c_size_t(n_frames), c_size_t(stride),
                                          c_void_p(d_out), c_void_p(stream) if stream else None))
+
+    def tune_scratch(self, d_iq: int, n_frames: int, d_out: int, candidates: int = 6, *,
+                     frame_stride: Optional[int] = None):
+        """Large-frame plans: try ``candidates`` placements of the two-pass scratch on this workload and keep the
+        fastest (``sdrk_plan_tune_scratch``).  Returns ``(probe_ms, chosen)``; ``d_out`` is overwritten."""
+        stride = self.nfft if frame_stride is None else int(frame_stride)
+        ms, chosen = (c_float * int(candidates))(), c_int(0)
+        with self._lock:
+            check(lib().sdrk_plan_tune_scratch(self.handle, c_void_p(d_iq), c_size_t(n_frames), c_size_t(stride),
+                                               c_void_p(d_out), int(candidates), ms, byref(chosen)))
+        return [float(v) for v in ms], int(chosen.value)
 
     def exec_device_timed_each(self, d_iq: int, n_frames: int, d_out: int, launches: int = 1, *,
                                frame_stride: Optional[int] = None) -> list:

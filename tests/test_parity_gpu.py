@@ -945,3 +945,38 @@ def test_plans_waterfalls_and_feature_calls_release_their_device_memory(pkg):
         one_round()
     free1 = free_bytes()
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 8 rounds"
+
+
+def test_scratch_placement_tuning_keeps_results_and_reports_probes(pkg):
+    """sdrk_plan_tune_scratch swaps the two-pass scratch of a large-frame plan for the fastest of a few candidates:
+    results before and after must be identical, every candidate must have been timed, and a one-pass plan
+    (no scratch) must return at once."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    n, rows, hop = 65536, 500, 32768
+    L = n + (rows - 1) * hop
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, ((L + 4095) // 4096) * 4096 * 8, ctypes.byref(d_in)))
+    _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_out)))
+    try:
+        _ffi.check(lib.sdrk_synth_fill(0, 11, 0, (L + 4095) // 4096, 4096, d_in, None))
+        a, b = np.empty((rows, n), np.float32), np.empty((rows, n), np.float32)
+        with SpectrumPlan(n, window="hann") as plan:
+            plan.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)
+            plan.sync()
+            _ffi.check(lib.sdrk_memcpy_d2h(0, a.ctypes.data_as(ctypes.c_void_p), d_out, a.nbytes))
+            probe, chosen = plan.tune_scratch(d_in.value, rows, d_out.value, 4, frame_stride=hop)
+            assert len(probe) == 4 and all(v > 0 for v in probe) and 0 <= chosen < 4
+            assert probe[chosen] == min(probe)
+            plan.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)
+            plan.sync()
+            _ffi.check(lib.sdrk_memcpy_d2h(0, b.ctypes.data_as(ctypes.c_void_p), d_out, b.nbytes))
+        assert np.array_equal(a, b)
+        with SpectrumPlan(4096) as small:
+            probe, chosen = small.tune_scratch(d_in.value, 16, d_out.value, 3)
+            assert probe == [0.0, 0.0, 0.0] and chosen == 0
+    finally:
+        lib.sdrk_dev_free(0, d_in)
+        lib.sdrk_dev_free(0, d_out)
