@@ -508,7 +508,14 @@ def main():
         tel.stop()
     after = tel.snapshot() if tel else None
     kernel_ms = float(sum(each_ms))
+    per_rank = None
     if dist is not None:
+        # every rank's own median launch and wall time, so that a straggler (placement level, clocks) shows in the line
+        mine = torch.tensor([_median(list(each_ms)), elapsed * 1e3 / args.steps], device=red_dev, dtype=torch.float64)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = {"launch_ms_median": [round(float(v[0]), 4) for v in everyone],
+                    "wall_ms_per_step": [round(float(v[1]), 4) for v in everyone]}
         t = torch.tensor([elapsed, kernel_ms], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -648,6 +655,9 @@ def main():
             "parity_frames_checked": n_checked,
             "placement": placement,
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+            line["aggregate_frac_of_n_gpu_peak"] = round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / (world * HBM_PEAK_GBPS), 4)
         if tel is not None:
             line["telemetry"] = {"before": before, "during": tel.summary(), "after": after,
                                  "source": tel.dir or "no sysfs node found for this device"}
