@@ -31,7 +31,7 @@ struct RowFeatShared {
     int i[4 * 7];
     unsigned hist[256];
     unsigned state[4];
-    unsigned long long flags[4];
+    unsigned long long flags[64];   // candidate bits of one 4096-bin stretch of the row
     int pk[2];
     double thr;
 };
@@ -293,38 +293,44 @@ __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatPa
     __syncthreads();
     if (!o_idx || !o_cnt) return;
 
-    // greedy peak scan, 256 candidates at a time; thread 0 applies the spacing rule in index order
+    // greedy peak scan.  All four waves mark the candidates of a 4096-bin stretch (64 ballot words in LDS), then wave 0
+    // applies the spacing rule in index order: two barriers per stretch instead of two per 256 bins.
     const double thr = sh.thr;
-    for (int base = 0; base < n; base += RF_THREADS) {
-        const int i = base + tid;
-        bool cand = false;
-        if (i >= 1 && i < n - 1) {
-            const float v = x[i];
-            cand = (double)v > thr && v > x[i - 1] && v > x[i + 1];
+    for (int sbase = 0; sbase < n; sbase += 4096) {
+#pragma unroll 4
+        for (int c = 0; c < 16; ++c) {
+            const int i = sbase + 256 * c + tid;
+            bool cand = false;
+            if (i >= 1 && i < n - 1) {
+                const float v = x[i];
+                cand = (double)v > thr && v > x[i - 1] && v > x[i + 1];
+            }
+            const unsigned long long b = __ballot(cand);
+            if (lane == 0) sh.flags[4 * c + wave] = b;
         }
-        const unsigned long long b = __ballot(cand);
-        if (lane == 0) sh.flags[wave] = b;
         __syncthreads();
         if (wave == 0) {
             // every lane of wave 0 runs the same scalar recurrence (SGPR operands: the flag words and the running
             // state are wave-uniform), lane 0 stores
             int last = __builtin_amdgcn_readfirstlane(sh.pk[0]), count = __builtin_amdgcn_readfirstlane(sh.pk[1]);
-            for (int w = 0; w < 4; ++w) {
+            const unsigned long long dspan = prm.min_distance >= 64 ? ~0ull : (1ull << (prm.min_distance > 0 ? prm.min_distance : 1)) - 1ull;
+            const int words = (n - sbase + 63) / 64 < 64 ? (n - sbase + 63) / 64 : 64;
+            for (int w = 0; w < words; ++w) {
                 const unsigned long long fw = sh.flags[w];
                 unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(fw >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)fw);
-                const int w0 = base + 64 * w;
+                const int w0 = sbase + 64 * w;
                 // candidates closer than min_distance to the last accepted peak are rejected wholesale: one short
                 // scalar iteration per ACCEPTED peak (noise rows have ~3 candidates per accepted one) that only
                 // marks it; the marked bits are turned into list entries by all 64 lanes at once afterwards
                 m = rf_clear_below(m, last + prm.min_distance - w0);
                 unsigned long long acc = 0;
-                while (m) {
-                    const int bit = __ffsll((long long)m) - 1;
-                    acc |= 1ull << bit;
-                    last = w0 + bit;
-                    m = rf_clear_below(m, bit + prm.min_distance);
+                while (m) {                  // dependent chain per accepted peak: find-first-one, shift, and-not
+                    const unsigned long long low = m & (0ull - m);      // lowest set bit
+                    acc |= low;
+                    m &= ~(low * dspan);     // low * (2^d - 1) = bits [bit, bit + d), truncated at 64
                 }
+                if (acc) last = w0 + 63 - __builtin_clzll(acc);
                 if ((acc >> lane) & 1ull) {
                     const int slot = count + __popcll(acc & ((1ull << lane) - 1ull));
                     if (slot < prm.max_peaks) o_idx[slot] = w0 + lane;
