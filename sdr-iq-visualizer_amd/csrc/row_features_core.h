@@ -33,6 +33,7 @@ struct RowFeatShared {
     unsigned state[4];
     unsigned long long flags[64];   // candidate bits of one 4096-bin stretch of the row
     int pk[2];
+    int list[64];                   // accepted peak indices waiting for one coalesced store
     double thr;
 };
 
@@ -311,14 +312,22 @@ __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatPa
         __syncthreads();
         if (wave == 0) {
             // every lane of wave 0 runs the same scalar recurrence (SGPR operands: the flag words and the running
-            // state are wave-uniform), lane 0 stores
+            // state are wave-uniform).  The 64 flag words are fetched by one LDS read (lane w holds word w) and
+            // handed out by v_readlane; accepted indices collect in an LDS list that leaves as one store per 64.
             int last = __builtin_amdgcn_readfirstlane(sh.pk[0]), count = __builtin_amdgcn_readfirstlane(sh.pk[1]);
+            int fill = 0;                                            // entries waiting in sh.list; count = stored so far
             const unsigned long long dspan = prm.min_distance >= 64 ? ~0ull : (1ull << (prm.min_distance > 0 ? prm.min_distance : 1)) - 1ull;
             const int words = (n - sbase + 63) / 64 < 64 ? (n - sbase + 63) / 64 : 64;
+            const unsigned long long mine = sh.flags[lane];
+            const int mine_lo = (int)(unsigned)mine, mine_hi = (int)(unsigned)(mine >> 32);
+            auto flush = [&]() {
+                if (lane < fill && count + lane < prm.max_peaks) o_idx[count + lane] = sh.list[lane];
+                count += fill;
+                fill = 0;
+            };
             for (int w = 0; w < words; ++w) {
-                const unsigned long long fw = sh.flags[w];
-                unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(fw >> 32)) << 32) |
-                                       (unsigned)__builtin_amdgcn_readfirstlane((int)fw);
+                unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mine_hi, w) << 32) |
+                                       (unsigned)__builtin_amdgcn_readlane(mine_lo, w);
                 const int w0 = sbase + 64 * w;
                 // candidates closer than min_distance to the last accepted peak are rejected wholesale: one short
                 // scalar iteration per ACCEPTED peak (noise rows have ~3 candidates per accepted one) that only
@@ -326,17 +335,19 @@ __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatPa
                 m = rf_clear_below(m, last + prm.min_distance - w0);
                 unsigned long long acc = 0;
                 while (m) {                  // dependent chain per accepted peak: find-first-one, shift, and-not
-                    const unsigned long long low = m & (0ull - m);      // lowest set bit
-                    acc |= low;
-                    m &= ~(low * dspan);     // low * (2^d - 1) = bits [bit, bit + d), truncated at 64
+                    const int bit = __builtin_ctzll(m);
+                    acc |= 1ull << bit;
+                    m &= ~(dspan << bit);
                 }
-                if (acc) last = w0 + 63 - __builtin_clzll(acc);
-                if ((acc >> lane) & 1ull) {
-                    const int slot = count + __popcll(acc & ((1ull << lane) - 1ull));
-                    if (slot < prm.max_peaks) o_idx[slot] = w0 + lane;
+                if (acc) {
+                    last = w0 + 63 - __builtin_clzll(acc);
+                    const int pc = __popcll(acc);
+                    if (fill + pc > 64) flush();
+                    if ((acc >> lane) & 1ull) sh.list[fill + __popcll(acc & ((1ull << lane) - 1ull))] = w0 + lane;
+                    fill += pc;
                 }
-                count += __popcll(acc);
             }
+            flush();
             if (lane == 0) { sh.pk[0] = last; sh.pk[1] = count; }
         }
         __syncthreads();
