@@ -733,9 +733,9 @@ def test_waterfall_decimated_readout(pkg):
 
 
 def test_fused_n65536_agrees_with_two_launch_path(pkg):
-    """The XCD-resident fused kernel (fft_fused64k.hip) does the same arithmetic as the two tiled
-    launches (differences: FMA contraction in separately compiled code, i.e. last-bit level); a stale
-    or early read of the L2-resident intermediate would be a gross error in a whole tile.
+    """The XCD-resident fused kernel (fft_fused64k.hip) runs the col / row code of the two tiled launches and must
+    agree with them (bit for bit on the host-array calls below); a stale or early read of the L2-resident
+    intermediate would be a gross error in a whole tile.
     3000 frames (1.5 GiB) keeps every XCD's ring wrapping hundreds of times under load."""
     import ctypes
     from sdr_iq_visualizer_amd import _ffi
@@ -765,6 +765,15 @@ def test_fused_n65536_agrees_with_two_launch_path(pkg):
                 assert peak_rel_err(a, b) <= 5e-6, f"frame {f} (stride {stride}) differs"   # one ulp of a 116 dB value is 9e-7
         fused.close()
         tiled.close()
+        # the other instantiations: rectangular window, complex epilogue, packed and 50 % overlapped host frames
+        rng = np.random.default_rng(5)
+        x = rand_c64(rng, 70, n, scale=4.0)                                # 70 frames: more than the 24 sets, uneven runs
+        stream = rand_c64(rng, 1, 40 * (n // 2) + n, scale=4.0)[0]
+        for window in (None, "hann"):
+            with SpectrumPlan(n, window=window, fused64k=True) as pf, SpectrumPlan(n, window=window) as pt:
+                assert np.array_equal(pf.fft(x), pt.fft(x)), f"complex epilogue, window={window}"
+                assert np.array_equal(pf.spectrum_db(x), pt.spectrum_db(x)), f"log epilogue, window={window}"
+                assert np.array_equal(pf.stft_db(stream, n // 2), pt.stft_db(stream, n // 2)), f"STFT, window={window}"
     finally:
         for d in (d_in, d_a, d_b):
             lib.sdrk_dev_free(0, d)
