@@ -632,6 +632,10 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
     p->eps = eps;
     p->shift = shift ? 1 : 0;
     p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* env = getenv("SDRK_NUM_CUS")) {   // size the persistent grids as for a smaller device (a partition
+        long v = atol(env);                           // mode, or the tests of the grid-smaller-than-work paths); selects no kernel
+        if (v >= 1 && v < p->num_cus) p->num_cus = (int)v;
+    }
 
 #define PLAN_TRY(expr)                                                                     \
     do {                                                                                   \

@@ -916,6 +916,28 @@ def test_one_process_per_gpu_path_under_torchrun(pkg, tmp_path):
     assert r.returncode == 0 and "rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("cus", [40, 96])
+def test_persistent_grids_smaller_than_the_device(pkg, monkeypatch, cus):
+    """Plans size their persistent grids from the CU count; on a partition of the device (or with SDRK_NUM_CUS)
+    the grids are smaller than the tile positions of the large-frame passes and every workgroup walks several
+    positions / runs — paths a full MI355X never takes.  Same results as the oracle."""
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    monkeypatch.setenv("SDRK_NUM_CUS", str(cus))
+    rng = np.random.default_rng(cus)
+    for n, b in ((4096, 700), (65536, 9), (1 << 18, 3), (1 << 20, 3), (1 << 21, 1)):
+        x = rand_c64(rng, b, n, scale=2.0)
+        with SpectrumPlan(n, window="hann") as p:
+            assert_db_parity(p.spectrum_db(x), cpu_ref.spectrum_db(x, window=np.hanning(n)), what=f"N={n} with {cus} CUs")
+    # The fused N = 65536 kernel sizes its sets of 32 workgroups per XCD from the CU count; with a count that
+    # does not describe the device the sets cannot all form, and the launch must END (bounded spins) and be
+    # reported as failed — never hang, never return rows silently.
+    from sdr_iq_visualizer_amd._ffi import SdrkError
+    x = rand_c64(rng, 40, 65536, scale=2.0)
+    with SpectrumPlan(65536, fused64k=True) as pf:
+        with pytest.raises(SdrkError, match="sets formed"):
+            pf.spectrum_db(x)
+
+
 # ---- resources --------------------------------------------------------------------------
 
 def test_plans_waterfalls_and_feature_calls_release_their_device_memory(pkg):
