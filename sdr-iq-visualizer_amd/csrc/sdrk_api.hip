@@ -119,6 +119,9 @@ struct sdrk_plan {
     // writes directly over PCIe (no DMA-engine copies for a 32 KiB frame)
     void* h_small_in = nullptr;
     void* h_small_out = nullptr;
+    uint32_t* h_small_flag = nullptr;   // completion word the stream writes behind a small call
+    void* d_small_flag = nullptr;
+    uint32_t small_seq = 0;
     // N = 65536 fused path (fft_fused64k.hip)
     bool fused64k = false;
     void* d_fused_ring = nullptr;
@@ -335,6 +338,16 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
         if (!p->h_small_in) {
             HIP_TRY(hipHostMalloc(&p->h_small_in, SMALL_IN_BYTES, hipHostMallocMapped));
             HIP_TRY(hipHostMalloc(&p->h_small_out, SMALL_IN_BYTES, hipHostMallocMapped));
+            void* f = nullptr;
+            if (hipHostMalloc(&f, 64, hipHostMallocMapped) == hipSuccess) {
+                memset(f, 0, 64);
+                p->h_small_flag = static_cast<uint32_t*>(f);
+                if (hipHostGetDevicePointer(&p->d_small_flag, f, 0) != hipSuccess) {
+                    (void)hipHostFree(f);
+                    p->h_small_flag = nullptr;
+                }
+            }
+            (void)hipGetLastError();
         }
         void *d_si = nullptr, *d_so = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&d_si, p->h_small_in, 0));
@@ -342,7 +355,25 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
         memcpy(p->h_small_in, iq, in_bytes);
         st = plan_launch(p, d_si, n_frames, frame_stride, d_so, epilogue, p->stream);
         if (st != SDRK_OK) return st;
-        HIP_TRY(hipStreamSynchronize(p->stream));
+        // Completion: the stream writes a sequence number into mapped host memory behind the kernel and the caller
+        // polls it — for a 10 us job the wake-up path of hipStreamSynchronize costs as much as the job.  Falls back
+        // to the synchronize after ~200 us of polling (or if the stream memory operation is not available).
+        static const bool poll_ok = getenv("SDRK_SMALL_NOPOLL") == nullptr;
+        bool done = false;
+        if (poll_ok && p->h_small_flag) {
+            const uint32_t seq = ++p->small_seq;
+            if (hipStreamWriteValue32(p->stream, p->d_small_flag, seq, 0) == hipSuccess) {
+                volatile uint32_t* flag = p->h_small_flag;
+                for (int spins = 0; spins < 200000; ++spins) {
+                    if (*flag == seq) { done = true; break; }
+                    __builtin_ia32_pause();
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (!done) HIP_TRY(hipStreamSynchronize(p->stream));
         memcpy(out, p->h_small_out, out_bytes);
         return SDRK_OK;
     }
@@ -765,6 +796,7 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (p->d_blu_b) (void)hipFree(p->d_blu_b);
     if (p->h_small_in) (void)hipHostFree(p->h_small_in);
     if (p->h_small_out) (void)hipHostFree(p->h_small_out);
+    if (p->h_small_flag) (void)hipHostFree(p->h_small_flag);
     if (p->d_fused_ring) (void)hipFree(p->d_fused_ring);
     if (p->d_fused_ctrl) (void)hipFree(p->d_fused_ctrl);
     if (p->h_fused_err) (void)hipHostFree(p->h_fused_err);

@@ -253,6 +253,9 @@ _plans_lock = threading.Lock()
 def _cached_plan(nfft: int, window: WindowArg, eps: float, shift: bool, device: int) -> SpectrumPlan:
     _, _, wkey = _window_spec(window, nfft)
     key = (int(device), int(nfft), wkey, float(eps), bool(shift))
+    plan = _plans.get(key)                      # (dict.get is atomic; the lock is only for creation)
+    if plan is not None:
+        return plan
     with _plans_lock:
         plan = _plans.get(key)
         if plan is None:
@@ -314,10 +317,20 @@ def freq_axis(n: int, sample_rate: float, center_freq: float = 0.0) -> np.ndarra
     n = int(n)
     if n < 1:
         raise ValueError("n must be >= 1")
-    d = 1 / sample_rate
-    val = 1.0 / (n * d)
-    k = np.arange(-(n // 2), (n - 1) // 2 + 1, dtype=int)
-    return k * val + center_freq
+    key = (n, sample_rate, center_freq)
+    cached = _freq_cache.get(key)
+    if cached is None:
+        d = 1 / sample_rate
+        val = 1.0 / (n * d)
+        k = np.arange(-(n // 2), (n - 1) // 2 + 1, dtype=int)
+        cached = k * val + center_freq
+        if len(_freq_cache) >= 8:               # the live app has one (n, fs, fc); keep a few
+            _freq_cache.clear()
+        _freq_cache[key] = cached
+    return cached.copy()                        # a fresh array per call, like the reference's expression
+
+
+_freq_cache: dict = {}
 
 
 def process_frame(samples, sample_rate: float, center_freq: float, *, window: WindowArg = None,
