@@ -29,4 +29,5 @@ print('%.4f  %.4f  %.4f  %.4f  %7.1f  %.4f  sclk_after %s  probe_ms %s chosen %d
 echo "== fused vs tiled N=65536 (4096 packed frames, then config 3; Hann)"
 { python3 tools/fused_probe.py 4096 65536 hann; python3 tools/fused_probe.py 18749 32768 hann; } > "$OUT/fused64k_vs_tiled.log" 2>&1
 cat "$OUT/fused64k_vs_tiled.log"; tail -3 "$OUT/placement_16_runs.txt"; tail -3 "$OUT/plain_alloc_8_runs.txt"
+echo "== one-frame host call"; python3 tools/small_call_probe.py > "$OUT/small_call_probe.log" 2>&1; cat "$OUT/small_call_probe.log"
 echo "== gpu tests"; python3 -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -2 "$OUT/pytest_gpu.log"
