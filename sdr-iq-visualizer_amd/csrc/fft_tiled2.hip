@@ -306,7 +306,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kerne
 #ifndef SDRK_COL_W256
 #define SDRK_COL_W256 16
 #endif
-// columns per col-pass tile; A = 1024 (and A = 512 when enabled) take col_pass_staged_kernel with STAGED_W columns
+// columns per col-pass tile; A = 512 and A = 1024 take col_pass_staged_kernel with STAGED_W columns
 #define STAGED_W(LOG2A) ((LOG2A) == 10 ? 8 : ((LOG2A) == 9 ? 16 : 0))
 #define COL_TILE_W(LOG2A) (STAGED_W(LOG2A) ? STAGED_W(LOG2A) : ((LOG2A) == 11 ? 8 : ((LOG2A) == 8 ? SDRK_COL_W256 : 16)))
 #define ROW_TILE_R(LOG2M) ((LOG2M) == 11 ? 8 : 16)
