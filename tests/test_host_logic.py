@@ -20,6 +20,19 @@ def test_freq_axis_bit_identical_to_reference_expression(n, fs, fc):
     assert np.array_equal(got, ref)
 
 
+def test_freq_axis_cache_hands_out_fresh_arrays():
+    """The axis is cached per (n, fs, fc) but every call returns its own array, as the reference's
+    expression does: a consumer that edits its copy must not change anybody else's; many distinct keys stay exact."""
+    a = spectrum.freq_axis(4096, 1_000_000, 2_400_000_000)
+    a[:] = 0.0
+    b = spectrum.freq_axis(4096, 1_000_000, 2_400_000_000)
+    assert b is not a and np.array_equal(b, cpu_ref.freq_axis(4096, 1_000_000, 2_400_000_000))
+    for k in range(20):                                   # more keys than the cache keeps
+        fs, fc = 1e6 + 7 * k, 1e9 + 13 * k
+        assert np.array_equal(spectrum.freq_axis(1000 + k, fs, fc), cpu_ref.freq_axis(1000 + k, fs, fc))
+    assert np.array_equal(spectrum.freq_axis(4096, 1_000_000, 2_400_000_000), b)
+
+
 def test_freq_axis_rejects_bad_n():
     with pytest.raises(ValueError):
         spectrum.freq_axis(0, 1e6, 0.0)
