@@ -429,6 +429,79 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS / NV, (NV > 1 ? 2 : (LdsCfg
     }
 }
 
+// row pass for M = 2048 with the log epilogue (N = 2^21, 2^22).  An 8-row tile fills the LDS, and as 8-row tiles the
+// rows leave in 32-byte pieces (row_pass_kernel<11, .., 8, 2>: 125 us per 192 MiB chunk, 2.4 TB/s).  This kernel
+// walks 16-row bands as two 8-row halves, keeps the first half's dB values in registers (32 per thread) and
+// writes both halves through one [M][17] float transpose tile — exactly the size of the exchange area — so that
+// the stores are the 64-byte pieces of the other row passes.  The registers that pays with are the ones the
+// generic kernel spends on its software prefetch, so the loads of a half are issued and awaited in place:
+// 115.4 -> 65.8 us per chunk all the same (4.6 TB/s of streamed bytes) — the 32-byte pieces were what cost.
+template <int LOG2M>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8 / 2, 2) void row_pass_pair_kernel(
+    const float2* __restrict__ scratch, float* __restrict__ out, size_t n_frames, int A,
+    const float2* __restrict__ twM, float eps, int shift) {
+    using C = LdsCfg<LOG2M>;
+    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, NV = 2, TR = T / NV, WGT = TR * 8;
+    static_assert((size_t)M * 17 * sizeof(float) <= (size_t)8 * C::SLOT * sizeof(float2), "transpose tile must fit the exchange area");
+    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
+    const int tid = threadIdx.x;
+    const int fr = tid / TR, rt = tid - fr * TR;
+    float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
+    LdsTw<LOG2M> tw[NV];
+#pragma unroll
+    for (int s = 0; s < NV; ++s) lds_tw_init<LOG2M>(tw[s], twM, rt + TR * s);
+    const size_t nfft = (size_t)A * M;
+    const int bands = A / 16;
+    const size_t items = n_frames * (size_t)bands;
+    const int xor_q = shift ? 8 : 0;
+    for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
+        const size_t f = g / bands;
+        const int k3_0 = (int)(g - f * bands) * 16;
+        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)k3_0 * M, (unsigned)(16 * M * 8));
+        float val[2][NV][16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            cf v[NV][16];
+#pragma unroll
+            for (int s = 0; s < NV; ++s) {
+                const int e0 = scratch_index(8 * h + fr, rt + TR * s, M);
+#pragma unroll
+                for (int i = 0; i < C0; ++i)
+#pragma unroll
+                    for (int j = 0; j < R0; ++j) {
+                        const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, 0));
+                        v[s][i * R0 + j] = cf{x.x, x.y};
+                    }
+            }
+            lds_fft_core_nv<LOG2M, 1, NV>(v, lds, 0, rt, tw);
+#pragma unroll
+            for (int s = 0; s < NV; ++s)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const cf z = v[s][rev16(q)];
+                    val[h][s][q] = logpsd_db(z.x, z.y, eps);
+                }
+        }
+        __syncthreads();  // all rows are through their last LDS reads: the exchange area becomes the transpose tile
+        float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][17]
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < NV; ++s)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) tile[(rt + TR * s + T * (q ^ xor_q)) * 17 + 8 * h + fr] = val[h][s][q];
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t ro = frame_rsrc(out + f * nfft + k3_0, (unsigned)((nfft - k3_0) * 4));
+        const int r = tid & 15, km0 = tid >> 4;                              // km = km0 + (WGT / 16) i
+#pragma unroll 8
+        for (int i = 0; i < 16 * M / WGT; ++i) {
+            const float x = tile[(km0 + (WGT / 16) * i) * 17 + r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), ro, (km0 * A + r) * 4, i * (WGT / 16) * A * 4, 2);
+        }
+        __syncthreads();  // tile reads done before the next band's exchanges
+    }
+}
+
 bool fft_tiled2_split(int nfft, int* log2a, int* log2m) {
     int lg = 0;
     while ((1 << lg) < nfft) ++lg;
@@ -523,9 +596,29 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
 
 #define ROW_NV(LOG2M) ((LOG2M) >= 10 ? 2 : 1)
 
+// row pass through row_pass_pair_kernel (M = 2048, log epilogue): one 512-thread workgroup per CU
+template <int LOG2M>
+static hipError_t launch_row_pair(const LaunchArgs& a, float* dst, size_t nf, int A) {
+    using C = LdsCfg<LOG2M>;
+    const size_t items = nf * (size_t)(A / 16);
+    const unsigned grid = (unsigned)(items < (size_t)a.num_cus ? items : (size_t)a.num_cus);
+    const size_t lds_bytes = (size_t)8 * C::SLOT * sizeof(float2);
+    const float2* twM = static_cast<const float2*>(a.d_twiddle_2p) + 2048;
+    auto kern = row_pass_pair_kernel<LOG2M>;
+    static std::atomic<uint64_t> lds_ok{0};   /* one bit per device */
+    hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * 8 / 2), lds_bytes, a.stream, static_cast<const float2*>(a.d_scratch), dst, nf, A,
+                       twM, a.eps, a.shift);
+    return hipGetLastError();
+}
+
 template <int LOG2M>
 static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, unsigned grid_cap) {
     using C = LdsCfg<LOG2M>;
+    if constexpr (LOG2M == 11) {
+        if (a.epilogue == EPI_LOGPSD) return launch_row_pair<LOG2M>(a, static_cast<float*>(dst), nf, A);
+    }
     constexpr int ROWS = ROW_TILE_R(LOG2M), NV = ROW_NV(LOG2M);
     // LDS: the exchange area (ROWS x 17/16 M complex) or the complex transpose tile (M x (ROWS+1)), whichever is larger
     const size_t xch = (size_t)ROWS * C::SLOT, tile = (size_t)C::N * (ROWS + 1);
