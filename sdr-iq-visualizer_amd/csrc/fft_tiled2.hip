@@ -429,19 +429,21 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS / NV, (NV > 1 ? 2 : (LdsCfg
     }
 }
 
-// row pass for M = 2048 with the log epilogue (N = 2^21, 2^22).  An 8-row tile fills the LDS, and as 8-row tiles the
-// rows leave in 32-byte pieces (row_pass_kernel<11, .., 8, 2>: 125 us per 192 MiB chunk, 2.4 TB/s).  This kernel
-// walks 16-row bands as two 8-row halves, keeps the first half's dB values in registers (32 per thread) and
-// writes both halves through one [M][17] float transpose tile — exactly the size of the exchange area — so that
-// the stores are the 64-byte pieces of the other row passes.  The registers that pays with are the ones the
-// generic kernel spends on its software prefetch, so the loads of a half are issued and awaited in place:
-// 115.4 -> 65.8 us per chunk all the same (4.6 TB/s of streamed bytes) — the 32-byte pieces were what cost.
-template <int LOG2M>
-__global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8 / 2, 2) void row_pass_pair_kernel(
+// row pass for M >= 1024 with the log epilogue (N = 2^19 ... 2^22).  A 16-row tile of M = 1024 (and an 8-row tile of
+// M = 2048) fills the LDS; the generic kernel answers that with 512-thread workgroups of two 16-point sets per
+// thread and a trickled register prefetch (66.5 us per 192 MiB chunk at M = 1024), and at M = 2048 its 8-row tiles
+// leave in 32-byte pieces (115 us, 2.4 TB/s).  This kernel is the plain alternative that turned out faster: it walks
+// 16-row bands as two 8-row HALVES, keeps the first half's dB values in registers (16 per thread) and writes both
+// halves through one [M][17] float transpose tile — exactly the size of the 8-row exchange area — so that the
+// stores are 64-byte pieces.  One 16-point set per thread, no prefetch, nothing to schedule by hand: at M = 1024 a
+// half is 64 KiB, TWO 512-thread workgroups share a CU (four waves per SIMD) and overlap each other: 55.0 us
+// (NV = 2: 61.0); at M = 2048 one 1024-thread workgroup: 61.5 us (NV = 2: 65.8).
+template <int LOG2M, int NV>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8 / NV, (LdsCfg<LOG2M>::T * 8 / NV >= 1024 ? 4 : (NV == 1 ? 4 : 2))) void row_pass_pair_kernel(
     const float2* __restrict__ scratch, float* __restrict__ out, size_t n_frames, int A,
     const float2* __restrict__ twM, float eps, int shift) {
     using C = LdsCfg<LOG2M>;
-    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, NV = 2, TR = T / NV, WGT = TR * 8;
+    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, TR = T / NV, WGT = TR * 8;
     static_assert((size_t)M * 17 * sizeof(float) <= (size_t)8 * C::SLOT * sizeof(float2), "transpose tile must fit the exchange area");
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
     const int tid = threadIdx.x;
@@ -596,19 +598,22 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
 
 #define ROW_NV(LOG2M) ((LOG2M) >= 10 ? 2 : 1)
 
-// row pass through row_pass_pair_kernel (M = 2048, log epilogue): one 512-thread workgroup per CU
+// row pass through row_pass_pair_kernel (M >= 1024, log epilogue): as many workgroups per CU as their LDS allows
 template <int LOG2M>
 static hipError_t launch_row_pair(const LaunchArgs& a, float* dst, size_t nf, int A) {
     using C = LdsCfg<LOG2M>;
     const size_t items = nf * (size_t)(A / 16);
-    const unsigned grid = (unsigned)(items < (size_t)a.num_cus ? items : (size_t)a.num_cus);
     const size_t lds_bytes = (size_t)8 * C::SLOT * sizeof(float2);
+    const size_t per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+    const size_t cap = (size_t)a.num_cus * per_cu;
+    const unsigned grid = (unsigned)(items < cap ? items : cap);
     const float2* twM = static_cast<const float2*>(a.d_twiddle_2p) + 2048;
-    auto kern = row_pass_pair_kernel<LOG2M>;
+    constexpr int NV = 1;
+    auto kern = row_pass_pair_kernel<LOG2M, NV>;
     static std::atomic<uint64_t> lds_ok{0};   /* one bit per device */
     hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);
     if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * 8 / 2), lds_bytes, a.stream, static_cast<const float2*>(a.d_scratch), dst, nf, A,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * 8 / NV), lds_bytes, a.stream, static_cast<const float2*>(a.d_scratch), dst, nf, A,
                        twM, a.eps, a.shift);
     return hipGetLastError();
 }
@@ -616,7 +621,7 @@ static hipError_t launch_row_pair(const LaunchArgs& a, float* dst, size_t nf, in
 template <int LOG2M>
 static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, unsigned grid_cap) {
     using C = LdsCfg<LOG2M>;
-    if constexpr (LOG2M == 11) {
+    if constexpr (LOG2M == 11 || LOG2M == 10) {
         if (a.epilogue == EPI_LOGPSD) return launch_row_pair<LOG2M>(a, static_cast<float*>(dst), nf, A);
     }
     constexpr int ROWS = ROW_TILE_R(LOG2M), NV = ROW_NV(LOG2M);
@@ -636,7 +641,11 @@ static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, u
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * ROWS / NV), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps, \
                            a.shift);                                                                             \
     } while (0)
-    if (a.epilogue == EPI_LOGPSD) SDRK_ROW(EPI_LOGPSD); else SDRK_ROW(EPI_COMPLEX);
+    if constexpr (LOG2M >= 10) {
+        SDRK_ROW(EPI_COMPLEX);               // (the log epilogue of these lengths went to row_pass_pair_kernel above)
+    } else {
+        if (a.epilogue == EPI_LOGPSD) SDRK_ROW(EPI_LOGPSD); else SDRK_ROW(EPI_COMPLEX);
+    }
 #undef SDRK_ROW
     return hipGetLastError();
 }
