@@ -231,8 +231,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's ring loads have returned
             if ((tid & 63) == 0) st_agent(row_done + (member - 16) * 4 + wave, s + 1);
-            lds_fft_core_nv<8, 1, 1>(reinterpret_cast<cf (&)[1][16]>(v), lds, 0, rt,
-                                     reinterpret_cast<const LdsTw<8> (&)[1]>(tw));
+            lds_fft_core<8, 1>(v, lds, 0, rt, tw);
             __syncthreads();  // all rows are through their last LDS reads: the buffer becomes the transpose tile
             if (EPILOGUE == EPI_LOGPSD) {
                 float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][17]

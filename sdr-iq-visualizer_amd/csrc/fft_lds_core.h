@@ -67,17 +67,6 @@ __device__ __forceinline__ void lds_tw_init(LdsTw<LOG2N>& tw, const float2* __re
     }
 }
 
-// The transform of one frame by T/NV threads, each playing NV "virtual threads" tau_s = rt + (T/NV) s of the
-// T-thread formulation (NV = 1: one 16-point set per thread; NV = 2: two, which halves the workgroup of a
-// 1024-point transform to 512 threads = two waves per SIMD and so doubles the registers a thread may use —
-// what the software-pipelined tile loops of fft_tiled2.hip need).
-// v[s][i*R0 + j] = x[tau_s + T (i + C0 j)] on entry (C0 = 16/R0); on return X[tau_s + T q] is in v[s][rev16(q)]
-// (for P == 1, i.e. N == 16: X[k] in v[0][rev16(k)]).  LDS element (inner address a) lives at
-// lds[a * IL + off]: IL = 1 with a per-frame base for frame-per-thread-group use, IL = 16 and
-// off = column for sixteen interleaved columns.  Contains 2 (P-1) workgroup barriers; the first
-// also protects the previous call's last reads.
-constexpr int LDS_HOOK_LAST_READS = -1;   // extra hook: the last pass has read its inputs, LDS is no longer needed
-
 // Workgroup barrier of the transform.  RAW = false: __syncthreads().  RAW = true: wait for this wave's own LDS
 // operations only, then s_barrier — for callers that keep an LDS-DMA (`buffer_load ... lds`) in flight across the
 // transform into a DIFFERENT part of LDS: __syncthreads() would make hipcc wait vmcnt(0) at every barrier and
@@ -94,125 +83,80 @@ __device__ __forceinline__ void lds_core_barrier() {
     }
 }
 
-struct NoHook {
-    __device__ __forceinline__ void operator()(int) const {}
-};
-
-// `hook(k)` is called at lds_core_hooks<LOG2N, NV>() points spread over the transform, k counting up in call
-// order: after each set's first-pass butterflies, after each exchange has been written, after each set's
-// radix-16 of the later passes — and once more with k = LDS_HOOK_LAST_READS when the last pass has issued its
-// LDS reads (from there on the transform works in registers only).  The tile loops use it to trickle the next tile's loads into the memory pipeline
-// instead of issuing them in one burst: a wave that issues 32 loads back to back sits in the issue stage until
-// the pipeline has taken them all, and with one workgroup per CU nothing else runs meanwhile (measured on the
-// M = 1024 row pass: 71.9 us per 24-frame chunk in one burst, 64.3 in two parts, 61.4 in four).
-template <int LOG2N, int NV>
-__host__ __device__ constexpr int lds_core_hooks() {
-    return LdsCfg<LOG2N>::P > 1 ? NV + (LdsCfg<LOG2N>::P - 1) * (1 + NV) : NV;
-}
-template <int LOG2N, int IL, int NV, class Hook = NoHook, bool RAW_BARRIER = false>
-__device__ __forceinline__ void lds_fft_core_nv(cf (&v)[NV][16], float2* __restrict__ lds, int off, int rt,
-                                                const LdsTw<LOG2N> (&tw)[NV], Hook&& hook = Hook()) {
+// The transform of one frame by T = N/16 threads, 16 points each.  v[i*R0 + j] = x[tau + T (i + C0 j)] on entry
+// (C0 = 16/R0); on return X[tau + T q] is in v[rev16(q)] (for P == 1, i.e. N == 16: X[k] in v[rev16(k)]).  LDS
+// element (inner address a) lives at lds[a * IL + off]: IL = 1 with a per-frame base for frame-per-thread-group
+// use, IL = W and off = column for W interleaved columns.  Contains 2 (P-1) workgroup barriers; the first also
+// protects the previous call's last reads.  RAW_BARRIER: see lds_core_barrier.
+template <int LOG2N, int IL, bool RAW_BARRIER = false>
+__device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ lds, int off, int tau,
+                                             const LdsTw<LOG2N>& tw) {
     using C = LdsCfg<LOG2N>;
     constexpr int N = C::N, P = C::P, R0 = C::R0, T = C::T;
-    constexpr int C0 = 16 / R0, TR = T / NV;
-    static_assert(T % NV == 0, "virtual threads must divide the thread count of the transform");
+    constexpr int C0 = 16 / R0;
+    if (R0 == 16) {
+        radix16(v);
+    } else {
 #pragma unroll
-    for (int s = 0; s < NV; ++s) {
-        if (R0 == 16) {
-            radix16(v[s]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < C0; ++i) small_bfly<R0>(v[s], i * R0);
-        }
-        hook(s);
+        for (int i = 0; i < C0; ++i) small_bfly<R0>(v, i * R0);
     }
     if (P > 1) {
+        if (R0 == 16) {
+            cf w[16], w1 = tw.w0[0];
+            asm volatile("" : "+v"(w1.x), "+v"(w1.y));  // keep the tree inside the frame loop (no LICM into 30 VGPRs)
+            pow_tree(w1, w);
 #pragma unroll
-        for (int s = 0; s < NV; ++s) {
-            if (R0 == 16) {
-                cf w[16], w1 = tw[s].w0[0];
-                asm volatile("" : "+v"(w1.x), "+v"(w1.y));  // keep the tree inside the frame loop (no LICM into 30 VGPRs)
-                pow_tree(w1, w);
+            for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
+        } else {
 #pragma unroll
-                for (int k = 1; k < 16; ++k) v[s][rev16(k)] = cmul(v[s][rev16(k)], w[k]);
-            } else {
+            for (int i = 0; i < C0; ++i) {
+                cf w1 = tw.w0[i], wk = w1;
 #pragma unroll
-                for (int i = 0; i < C0; ++i) {
-                    cf w1 = tw[s].w0[i], wk = w1;
-#pragma unroll
-                    for (int k = 1; k < R0; ++k) {
-                        v[s][i * R0 + k] = cmul(v[s][i * R0 + k], wk);
-                        if (k + 1 < R0) wk = cmul(wk, w1);
-                    }
+                for (int k = 1; k < R0; ++k) {
+                    v[i * R0 + k] = cmul(v[i * R0 + k], wk);
+                    if (k + 1 < R0) wk = cmul(wk, w1);
                 }
             }
         }
         lds_core_barrier<RAW_BARRIER>();  // previous transform's last-pass reads are done
         constexpr int S1 = C::Mp(0) + C::pad(1);
 #pragma unroll
-        for (int s = 0; s < NV; ++s) {
-            const int tau = rt + TR * s;
+        for (int i = 0; i < C0; ++i)
 #pragma unroll
-            for (int i = 0; i < C0; ++i)
-#pragma unroll
-                for (int k = 0; k < R0; ++k) {
-                    const cf z = v[s][i * R0 + (R0 == 16 ? rev16(k) : k)];
-                    lds[((tau + T * i) + S1 * k) * IL + off] = make_float2(z.x, z.y);
-                }
-        }
-        hook(NV);
+            for (int k = 0; k < R0; ++k) {
+                const cf z = v[i * R0 + (R0 == 16 ? rev16(k) : k)];
+                lds[((tau + T * i) + S1 * k) * IL + off] = make_float2(z.x, z.y);
+            }
         lds_core_barrier<RAW_BARRIER>();
     }
 #pragma unroll
     for (int p = 1; p < P; ++p) {
         const int Mq = C::Mp(p);
         const int Sin = C::Mp(p - 1) + C::pad(p);
+        const int Kin = tau / Mq, rr = tau - Kin * Mq;
 #pragma unroll
-        for (int s = 0; s < NV; ++s) {
-            const int tau = rt + TR * s;
-            const int Kin = tau / Mq, rr = tau - Kin * Mq;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float2 t = lds[(rr + Mq * j + Sin * Kin) * IL + off];
-                v[s][j] = cf{t.x, t.y};
-            }
-            if (p == P - 1 && s == NV - 1) hook(LDS_HOOK_LAST_READS);
-            radix16(v[s]);
-            hook(NV + 1 + (p - 1) * (1 + NV) + s);
-            if (p < P - 1) {
-                cf w[16], w1 = tw[s].wp[p];
-                asm volatile("" : "+v"(w1.x), "+v"(w1.y));
-                pow_tree(w1, w);
-#pragma unroll
-                for (int k = 1; k < 16; ++k) v[s][rev16(k)] = cmul(v[s][rev16(k)], w[k]);
-            }
+        for (int j = 0; j < 16; ++j) {
+            const float2 t = lds[(rr + Mq * j + Sin * Kin) * IL + off];
+            v[j] = cf{t.x, t.y};
         }
+        radix16(v);
         if (p < P - 1) {
+            cf w[16], w1 = tw.wp[p];
+            asm volatile("" : "+v"(w1.x), "+v"(w1.y));
+            pow_tree(w1, w);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
             lds_core_barrier<RAW_BARRIER>();  // everyone has read the layout entering pass p
             const int Sout = Mq + C::pad(p + 1);
             const int kstep = N / C::Np(p);
 #pragma unroll
-            for (int s = 0; s < NV; ++s) {
-                const int tau = rt + TR * s;
-                const int Kin = tau / Mq, rr = tau - Kin * Mq;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const cf z = v[s][rev16(k)];
-                    lds[(rr + Sout * (Kin + kstep * k)) * IL + off] = make_float2(z.x, z.y);
-                }
+            for (int k = 0; k < 16; ++k) {
+                const cf z = v[rev16(k)];
+                lds[(rr + Sout * (Kin + kstep * k)) * IL + off] = make_float2(z.x, z.y);
             }
-            hook(NV + 1 + (p - 1) * (1 + NV) + NV);
             lds_core_barrier<RAW_BARRIER>();
         }
     }
-}
-
-// one 16-point set per thread (tau = thread index inside the frame): the form fft_lds.hip and bluestein.hip use
-template <int LOG2N, int IL>
-__device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ lds, int off, int tau,
-                                             const LdsTw<LOG2N>& tw) {
-    lds_fft_core_nv<LOG2N, IL, 1>(reinterpret_cast<cf (&)[1][16]>(v), lds, off, tau,
-                                  reinterpret_cast<const LdsTw<LOG2N> (&)[1]>(tw));
 }
 
 // Scratch layout between the passes.  The col pass produces, per workgroup, all A values of k3 for W adjacent

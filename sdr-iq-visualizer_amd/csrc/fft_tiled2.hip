@@ -12,7 +12,8 @@
 //              in 16 x 16 squares (scratch_index below)
 //   row pass   tile = 16 adjacent k3 rows x M (each row contiguous): DFT-M per row, fftshift
 //              (km + M/2), log epilogue, then a 16 x M transpose through LDS so that the stores
-//              X[A km + k3] run along k3 (64-byte segments)
+//              X[A km + k3] run along k3 (64-byte segments); M >= 1024: the 16 rows as two 8-row halves
+//              (row_pass_pair_kernel)
 // 28 B/sample of traffic (8 in, 8+8 scratch, 4 out); the scratch is processed in chunks that stay in the
 // 256 MiB Infinity Cache between the pass that writes them and the pass that reads them.
 #include "fft_lds_core.h"
@@ -289,8 +290,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kerne
                 }
             lds_core_barrier<true>();                                      // every wave has picked its samples up
             dma(f + 1);
-            lds_fft_core_nv<LOG2A, W, 1, NoHook, true>(reinterpret_cast<cf (&)[1][16]>(v), xch, fr, tau,
-                                                       reinterpret_cast<const LdsTw<LOG2A> (&)[1]>(tw));
+            lds_fft_core<LOG2A, W, true>(v, xch, fr, tau, tw);
             const __amdgpu_buffer_rsrc_t ro = frame_rsrc(scratch + f * nfft, (unsigned)(nfft * 8));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -309,123 +309,75 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kerne
 // columns per col-pass tile; A = 512 and A = 1024 take col_pass_staged_kernel with STAGED_W columns
 #define STAGED_W(LOG2A) ((LOG2A) == 10 ? 8 : ((LOG2A) == 9 ? 16 : 0))
 #define COL_TILE_W(LOG2A) (STAGED_W(LOG2A) ? STAGED_W(LOG2A) : ((LOG2A) == 11 ? 8 : ((LOG2A) == 8 ? SDRK_COL_W256 : 16)))
-#define ROW_TILE_R(LOG2M) ((LOG2M) == 11 ? 8 : 16)
 
-// ROWS = rows per tile (16, or 8 for M = 2048 so that the tile fits the LDS).
-// NV = 16-point sets per thread (fft_lds_core.h): 1, or 2 for M >= 1024, where one tile fills the LDS and a CU
-// holds a single workgroup.  With 1024 threads that workgroup is capped at 128 VGPRs and runs load -> transform ->
-// store strictly in sequence (measured at N = 2^20: 4.4 TB/s of streamed bytes against 5.9 for M = 256, where four
-// workgroups per CU overlap each other).  With NV = 2 the same tile takes 512 threads = two waves per SIMD and up
-// to 256 VGPRs each, enough to keep the NEXT tile's 32 loads per thread in flight across the current tile's
-// passes (the software pipeline of the col pass above).
-template <int LOG2M, int EPILOGUE, int ROWS, int NV>
-__global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS / NV, (NV > 1 ? 2 : (LdsCfg<LOG2M>::T * ROWS >= 512 ? 4 : 3))) void row_pass_kernel(
+// row pass for M = 256 and 512: tile = 16 adjacent k3 rows x M (34.8 / 69.6 KiB of LDS: four / two workgroups per
+// CU, which overlap each other's load, transform and store phases).
+template <int LOG2M, int EPILOGUE>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 512 ? 4 : 3)) void row_pass_kernel(
     const float2* __restrict__ scratch, void* __restrict__ out_raw, size_t n_frames, int A,
     const float2* __restrict__ twM, float eps, int shift) {
     using C = LdsCfg<LOG2M>;
-    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, TR = T / NV;
-    constexpr bool PREFETCH = NV > 1;
+    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, ROWS = 16, WGT = T * ROWS;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 16 rows x SLOT, reused for the transpose
     const int tid = threadIdx.x;
-    const int fr = tid / TR, rt = tid - fr * TR;
+    const int fr = tid / T, rt = tid - fr * T;
     float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
-    LdsTw<LOG2M> tw[NV];
-#pragma unroll
-    for (int s = 0; s < NV; ++s) lds_tw_init<LOG2M>(tw[s], twM, rt + TR * s);
+    LdsTw<LOG2M> tw;
+    lds_tw_init<LOG2M>(tw, twM, rt);
     const size_t nfft = (size_t)A * M;
     const int tiles = A / ROWS;
     const size_t items = n_frames * (size_t)tiles;
     const int xor_q = shift ? 8 : 0;
-    constexpr int WGT = TR * ROWS;   // threads
-
-    // the 16 NV loads of one tile.  Rows k3_0 .. k3_0+ROWS-1: the descriptor covers the 16-row band they lie in
-    // (for ROWS = 8 the tile is half of it; zero-sized when there is no such item: the loads return zeros without
-    // touching memory); element (k3_0 + fr, m = tau_s + T c): lane part from (k3 & 15, tau_s), uniform part from T c
-    // PART of NPARTS: which of the 16 NV loads to issue (all of them when NPARTS == 1)
-    auto issue_part = [&](size_t it, v2f (&x)[NV][16], int part, int nparts) {
-        const bool live = it < items;
-        const size_t f = live ? it / tiles : 0;
-        const int k3_0 = live ? (int)(it - f * tiles) * ROWS : 0;
-        const int band = k3_0 & ~15;
-        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)band * M, live ? (unsigned)(16 * M * 8) : 0u);
-#pragma unroll
-        for (int s = 0; s < NV; ++s) {
-            const int e0 = scratch_index((k3_0 & 15) + fr, rt + TR * s, M);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                if ((s * 16 + c) * nparts / (16 * NV) != part) continue;
-                x[s][c] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, c * T, M) * 8, 0));
-            }
-        }
-    };
-    auto issue = [&](size_t it, v2f (&x)[NV][16]) { issue_part(it, x, 0, 1); };
-    // issue points of the prefetch: the loop top and every hook of the transform (fft_lds_core.h)
-    constexpr int NPARTS = PREFETCH ? 1 + lds_core_hooks<LOG2M, NV>() : 1;
-
-    v2f xa[NV][16], xb[NV][16];
-    if (PREFETCH) issue(blockIdx.x, xa);
+    const int e0 = scratch_index(fr, rt, M);          // element (k3_0 + fr, m = rt + T c): lane part; uniform part from T c
     for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
         const size_t f = it / tiles;
         const int k3_0 = (int)(it - f * tiles) * ROWS;
-        const size_t nxt = it + gridDim.x;
-        if (PREFETCH) issue_part(nxt, xb, 0, NPARTS);
-        else issue(it, xa);
-        cf v[NV][16];
+        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)k3_0 * M, (unsigned)(16 * M * 8));
+        cf v[16];
 #pragma unroll
-        for (int s = 0; s < NV; ++s)
+        for (int i = 0; i < C0; ++i)
 #pragma unroll
-            for (int i = 0; i < C0; ++i)
-#pragma unroll
-                for (int j = 0; j < R0; ++j) v[s][i * R0 + j] = cf{xa[s][i + C0 * j].x, xa[s][i + C0 * j].y};
-        lds_fft_core_nv<LOG2M, 1, NV>(v, lds, 0, rt, tw, [&](int k) {
-            if (PREFETCH && k >= 0) issue_part(nxt, xb, k + 1, NPARTS);
-        });
+            for (int j = 0; j < R0; ++j) {
+                const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, 0));
+                v[i * R0 + j] = cf{x.x, x.y};
+            }
+        lds_fft_core<LOG2M, 1>(v, lds, 0, rt, tw);
         __syncthreads();  // all rows are through their last LDS reads: the buffer becomes the transpose tile
         if (EPILOGUE == EPI_LOGPSD) {
             float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][ROWS + 1]
 #pragma unroll
-            for (int s = 0; s < NV; ++s)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const cf z = v[s][rev16(q)];
-                    tile[(rt + TR * s + T * (q ^ xor_q)) * (ROWS + 1) + fr] = logpsd_db(z.x, z.y, eps);
-                }
+            for (int q = 0; q < 16; ++q) {
+                const cf z = v[rev16(q)];
+                tile[(rt + T * (q ^ xor_q)) * (ROWS + 1) + fr] = logpsd_db(z.x, z.y, eps);
+            }
             __syncthreads();
             const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float*>(out_raw) + f * nfft + k3_0,
                                                          (unsigned)((nfft - k3_0) * 4));
-            // element e = tid + WGT i of the ROWS x M tile: row r = e % ROWS (lanes), km = e / ROWS = tid / ROWS + TR i
+            // element e = tid + WGT i of the ROWS x M tile: row r = e % ROWS (lanes), km = e / ROWS = tid / ROWS + T i
             const int r = tid & (ROWS - 1), km0 = tid / ROWS;
 #pragma unroll
-            for (int i = 0; i < 16 * NV; ++i) {
-                const float val = tile[(km0 + TR * i) * (ROWS + 1) + r];
+            for (int i = 0; i < 16; ++i) {
+                const float val = tile[(km0 + T * i) * (ROWS + 1) + r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, (km0 * A + r) * 4,
-                                                      i * TR * A * 4, 2);
+                                                      i * T * A * 4, 2);
             }
         } else {
             float2* __restrict__ tile = lds_all;  // [km][ROWS + 1]
 #pragma unroll
-            for (int s = 0; s < NV; ++s)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const cf z = v[s][rev16(q)];
-                    tile[(rt + TR * s + T * (q ^ xor_q)) * (ROWS + 1) + fr] = make_float2(z.x, z.y);
-                }
+            for (int q = 0; q < 16; ++q) {
+                const cf z = v[rev16(q)];
+                tile[(rt + T * (q ^ xor_q)) * (ROWS + 1) + fr] = make_float2(z.x, z.y);
+            }
             __syncthreads();
             float2* __restrict__ o = static_cast<float2*>(out_raw) + f * nfft + k3_0;
 #pragma unroll
-            for (int i = 0; i < 16 * NV; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 const int e = tid + WGT * i;
                 const int r = e & (ROWS - 1), km = e / ROWS;
                 o[(size_t)km * A + r] = tile[km * (ROWS + 1) + r];
             }
         }
         __syncthreads();  // tile reads done before the next item's exchanges
-        if (PREFETCH) {
-#pragma unroll
-            for (int s = 0; s < NV; ++s)
-#pragma unroll
-                for (int c = 0; c < 16; ++c) xa[s][c] = xb[s][c];
-        }
     }
 }
 
@@ -437,21 +389,21 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * ROWS / NV, (NV > 1 ? 2 : (LdsCfg
 // halves through one [M][17] float transpose tile — exactly the size of the 8-row exchange area — so that the
 // stores are 64-byte pieces.  One 16-point set per thread, no prefetch, nothing to schedule by hand: at M = 1024 a
 // half is 64 KiB, TWO 512-thread workgroups share a CU (four waves per SIMD) and overlap each other: 55.0 us
-// (NV = 2: 61.0); at M = 2048 one 1024-thread workgroup: 61.5 us (NV = 2: 65.8).
-template <int LOG2M, int NV>
-__global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8 / NV, (LdsCfg<LOG2M>::T * 8 / NV >= 1024 ? 4 : (NV == 1 ? 4 : 2))) void row_pass_pair_kernel(
-    const float2* __restrict__ scratch, float* __restrict__ out, size_t n_frames, int A,
+// (two sets per thread: 61.0); at M = 2048 one 1024-thread workgroup: 61.5 us (two sets: 65.8).  The complex
+// epilogue (fft_c64) takes the same kernel: its 8-row halves are 64-byte pieces as they are.
+template <int LOG2M, int EPILOGUE>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
+    const float2* __restrict__ scratch, void* __restrict__ out_raw, size_t n_frames, int A,
     const float2* __restrict__ twM, float eps, int shift) {
     using C = LdsCfg<LOG2M>;
-    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, TR = T / NV, WGT = TR * 8;
+    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, WGT = T * 8;
     static_assert((size_t)M * 17 * sizeof(float) <= (size_t)8 * C::SLOT * sizeof(float2), "transpose tile must fit the exchange area");
-    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
+    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];   // 8 x SLOT; complex epilogue: at least [M][9] float2
     const int tid = threadIdx.x;
-    const int fr = tid / TR, rt = tid - fr * TR;
+    const int fr = tid / T, rt = tid - fr * T;
     float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
-    LdsTw<LOG2M> tw[NV];
-#pragma unroll
-    for (int s = 0; s < NV; ++s) lds_tw_init<LOG2M>(tw[s], twM, rt + TR * s);
+    LdsTw<LOG2M> tw;
+    lds_tw_init<LOG2M>(tw, twM, rt);
     const size_t nfft = (size_t)A * M;
     const int bands = A / 16;
     const size_t items = n_frames * (size_t)bands;
@@ -460,47 +412,62 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8 / NV, (LdsCfg<LOG2M>::T * 8 / 
         const size_t f = g / bands;
         const int k3_0 = (int)(g - f * bands) * 16;
         const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)k3_0 * M, (unsigned)(16 * M * 8));
-        float val[2][NV][16];
+        float val[2][16];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            cf v[NV][16];
+            cf v[16];
+            const int e0 = scratch_index(8 * h + fr, rt, M);
 #pragma unroll
-            for (int s = 0; s < NV; ++s) {
-                const int e0 = scratch_index(8 * h + fr, rt + TR * s, M);
+            for (int i = 0; i < C0; ++i)
 #pragma unroll
-                for (int i = 0; i < C0; ++i)
-#pragma unroll
-                    for (int j = 0; j < R0; ++j) {
-                        const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, 0));
-                        v[s][i * R0 + j] = cf{x.x, x.y};
-                    }
-            }
-            lds_fft_core_nv<LOG2M, 1, NV>(v, lds, 0, rt, tw);
-#pragma unroll
-            for (int s = 0; s < NV; ++s)
+                for (int j = 0; j < R0; ++j) {
+                    const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, 0));
+                    v[i * R0 + j] = cf{x.x, x.y};
+                }
+            lds_fft_core<LOG2M, 1>(v, lds, 0, rt, tw);
+            if (EPILOGUE == EPI_LOGPSD) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const cf z = v[s][rev16(q)];
-                    val[h][s][q] = logpsd_db(z.x, z.y, eps);
+                    const cf z = v[rev16(q)];
+                    val[h][q] = logpsd_db(z.x, z.y, eps);
                 }
-        }
-        __syncthreads();  // all rows are through their last LDS reads: the exchange area becomes the transpose tile
-        float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][17]
+            } else {
+                // complex rows: 8 rows x 8 bytes are 64-byte pieces already; each half leaves through its own [M][9] tile
+                __syncthreads();
+                float2* __restrict__ tile = lds_all;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int s = 0; s < NV; ++s)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) tile[(rt + TR * s + T * (q ^ xor_q)) * 17 + 8 * h + fr] = val[h][s][q];
-        __syncthreads();
-        const __amdgpu_buffer_rsrc_t ro = frame_rsrc(out + f * nfft + k3_0, (unsigned)((nfft - k3_0) * 4));
-        const int r = tid & 15, km0 = tid >> 4;                              // km = km0 + (WGT / 16) i
+                for (int q = 0; q < 16; ++q) {
+                    const cf z = v[rev16(q)];
+                    tile[(rt + T * (q ^ xor_q)) * 9 + fr] = make_float2(z.x, z.y);
+                }
+                __syncthreads();
+                float2* __restrict__ o = static_cast<float2*>(out_raw) + f * nfft + k3_0 + 8 * h;
 #pragma unroll 8
-        for (int i = 0; i < 16 * M / WGT; ++i) {
-            const float x = tile[(km0 + (WGT / 16) * i) * 17 + r];
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), ro, (km0 * A + r) * 4, i * (WGT / 16) * A * 4, 2);
+                for (int i = 0; i < 8 * M / WGT; ++i) {
+                    const int e = tid + WGT * i;
+                    const int r = e & 7, km = e >> 3;
+                    o[(size_t)km * A + r] = tile[km * 9 + r];
+                }
+                __syncthreads();  // tile reads done before the next half's exchanges
+            }
         }
-        __syncthreads();  // tile reads done before the next band's exchanges
+        if (EPILOGUE == EPI_LOGPSD) {
+            __syncthreads();  // all rows are through their last LDS reads: the exchange area becomes the transpose tile
+            float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][17]
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) tile[(rt + T * (q ^ xor_q)) * 17 + 8 * h + fr] = val[h][q];
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float*>(out_raw) + f * nfft + k3_0, (unsigned)((nfft - k3_0) * 4));
+            const int r = tid & 15, km0 = tid >> 4;                              // km = km0 + (WGT / 16) i
+#pragma unroll 8
+            for (int i = 0; i < 16 * M / WGT; ++i) {
+                const float x = tile[(km0 + (WGT / 16) * i) * 17 + r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), ro, (km0 * A + r) * 4, i * (WGT / 16) * A * 4, 2);
+            }
+            __syncthreads();  // tile reads done before the next band's exchanges
+        }
     }
 }
 
@@ -596,58 +563,59 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
     else return launch_col_tiles<LOG2A>(a, src, nf, M, grid_cap);
 }
 
-#define ROW_NV(LOG2M) ((LOG2M) >= 10 ? 2 : 1)
 
-// row pass through row_pass_pair_kernel (M >= 1024, log epilogue): as many workgroups per CU as their LDS allows
+// row pass through row_pass_pair_kernel (M >= 1024): as many workgroups per CU as their LDS allows
 template <int LOG2M>
-static hipError_t launch_row_pair(const LaunchArgs& a, float* dst, size_t nf, int A) {
+static hipError_t launch_row_pair(const LaunchArgs& a, void* dst, size_t nf, int A) {
     using C = LdsCfg<LOG2M>;
     const size_t items = nf * (size_t)(A / 16);
-    const size_t lds_bytes = (size_t)8 * C::SLOT * sizeof(float2);
+    const size_t xch = (size_t)8 * C::SLOT * sizeof(float2), ctile = (size_t)C::N * 9 * sizeof(float2);
+    const size_t lds_bytes = a.epilogue == EPI_LOGPSD ? xch : (xch > ctile ? xch : ctile);
     const size_t per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
     const size_t cap = (size_t)a.num_cus * per_cu;
     const unsigned grid = (unsigned)(items < cap ? items : cap);
     const float2* twM = static_cast<const float2*>(a.d_twiddle_2p) + 2048;
-    constexpr int NV = 1;
-    auto kern = row_pass_pair_kernel<LOG2M, NV>;
-    static std::atomic<uint64_t> lds_ok{0};   /* one bit per device */
-    hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);
-    if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * 8 / NV), lds_bytes, a.stream, static_cast<const float2*>(a.d_scratch), dst, nf, A,
-                       twM, a.eps, a.shift);
+#define SDRK_ROWP(E)                                                                                             \
+    do {                                                                                                         \
+        auto kern = row_pass_pair_kernel<LOG2M, E>;                                                              \
+        static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                     \
+        hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
+        if (e0 != hipSuccess) return e0;                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * 8), lds_bytes, a.stream, static_cast<const float2*>(a.d_scratch), dst, nf, \
+                           A, twM, a.eps, a.shift);                                                              \
+    } while (0)
+    if (a.epilogue == EPI_LOGPSD) SDRK_ROWP(EPI_LOGPSD); else SDRK_ROWP(EPI_COMPLEX);
+#undef SDRK_ROWP
     return hipGetLastError();
 }
 
 template <int LOG2M>
 static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, unsigned grid_cap) {
     using C = LdsCfg<LOG2M>;
-    if constexpr (LOG2M == 11 || LOG2M == 10) {
-        if (a.epilogue == EPI_LOGPSD) return launch_row_pair<LOG2M>(a, static_cast<float*>(dst), nf, A);
-    }
-    constexpr int ROWS = ROW_TILE_R(LOG2M), NV = ROW_NV(LOG2M);
-    // LDS: the exchange area (ROWS x 17/16 M complex) or the complex transpose tile (M x (ROWS+1)), whichever is larger
-    const size_t xch = (size_t)ROWS * C::SLOT, tile = (size_t)C::N * (ROWS + 1);
-    const size_t lds_bytes = (xch > tile ? xch : tile) * sizeof(float2);
-    const size_t items = nf * (size_t)(A / ROWS);
-    const unsigned grid = (unsigned)(items < grid_cap ? items : grid_cap);
-    const float2* twM = static_cast<const float2*>(a.d_twiddle_2p) + 2048;
-    const float2* scratch = static_cast<const float2*>(a.d_scratch);
+    if constexpr (LOG2M >= 10) {
+        return launch_row_pair<LOG2M>(a, dst, nf, A);
+    } else {
+        constexpr int ROWS = 16;
+        // LDS: the exchange area (ROWS x 17/16 M complex) or the complex transpose tile (M x (ROWS+1)), whichever is larger
+        const size_t xch = (size_t)ROWS * C::SLOT, tile = (size_t)C::N * (ROWS + 1);
+        const size_t lds_bytes = (xch > tile ? xch : tile) * sizeof(float2);
+        const size_t items = nf * (size_t)(A / ROWS);
+        const unsigned grid = (unsigned)(items < grid_cap ? items : grid_cap);
+        const float2* twM = static_cast<const float2*>(a.d_twiddle_2p) + 2048;
+        const float2* scratch = static_cast<const float2*>(a.d_scratch);
 #define SDRK_ROW(E)                                                                                              \
     do {                                                                                                         \
-        auto kern = row_pass_kernel<LOG2M, E, ROWS, NV>;                                                          \
+        auto kern = row_pass_kernel<LOG2M, E>;                                                                   \
         static std::atomic<uint64_t> lds_ok{0};   /* per instantiation, one bit per device */                     \
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
         if (e0 != hipSuccess) return e0;                                                                         \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * ROWS / NV), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * ROWS), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps, \
                            a.shift);                                                                             \
     } while (0)
-    if constexpr (LOG2M >= 10) {
-        SDRK_ROW(EPI_COMPLEX);               // (the log epilogue of these lengths went to row_pass_pair_kernel above)
-    } else {
         if (a.epilogue == EPI_LOGPSD) SDRK_ROW(EPI_LOGPSD); else SDRK_ROW(EPI_COMPLEX);
-    }
 #undef SDRK_ROW
-    return hipGetLastError();
+        return hipGetLastError();
+    }
 }
 
 hipError_t launch_fft_tiled2(const LaunchArgs& a) {
@@ -673,12 +641,12 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
     size_t chunk = a.scratch_frames;
     {
         auto gcd = [](size_t x, size_t y) { while (y) { size_t t = x % y; x = y; y = t; } return x; };
-        const int Wc = COL_TILE_W(la <= 11 ? la : 11), Rr = ROW_TILE_R(lm <= 11 ? lm : 11);
+        const int Wc = COL_TILE_W(la <= 11 ? la : 11), Rr = 16;
         const bool pipelined = (A / 16) * Wc <= 256 && Wc >= 16;
         size_t col_grid = STAGED_W(la) ? (size_t)a.num_cus
                         : (Wc == 8 ? (size_t)a.num_cus * 2 : (pipelined ? (size_t)a.num_cus * 3 : cap(A < 1024 ? A : 1024)));
         if (pipelined && col_grid > cap(A)) col_grid = cap(A);
-        const size_t row_grid = cap(M < 1024 ? M : 1024);
+        const size_t row_grid = M >= 2048 ? (size_t)a.num_cus : (M == 1024 ? (size_t)a.num_cus * 2 : cap(M));
         size_t cw = col_grid / (size_t)(M / Wc), rw = row_grid / (size_t)(A / Rr);
         if (cw < 1) cw = 1;
         if (rw < 1) rw = 1;
