@@ -580,7 +580,7 @@ def main():
             r = device_config(lib, _ffi, SpectrumPlan, dev, 65536, 1 + (L - 65536) // 32768, 32768, "hann", 7)
             r["realtime_factor_at_61.44_Msps"] = round(10.0 / (r["ms"] * 1e-3), 1)
             r["workload"] = "BASELINE.json configs[2]: waterfall STFT N=65536, 50 % overlap, 10 s @ 61.44 Msps"
-            r["kernels"] = "sdrk::col_pass_kernel<8> + sdrk::row_pass_kernel<8> per 384-frame chunk (192 MiB scratch)"
+            r["kernels"] = "sdrk::col_pass_kernel<8,..> + sdrk::row_pass_kernel<8,0> per 384-frame chunk (192 MiB scratch)"
             secondary["config3"] = r
             r = device_config(lib, _ffi, SpectrumPlan, dev, 1 << 20, 256, 1 << 20, "hann", 7)
             r["workload"] = "BASELINE.json configs[4], one channel: 256 back-to-back N=2^20 frames"
