@@ -475,7 +475,11 @@ bool fft_tiled2_split(int nfft, int* log2a, int* log2m) {
     int lg = 0;
     while ((1 << lg) < nfft) ++lg;
     if ((1 << lg) != nfft || lg < 15 || lg > 22) return false;
-    const int la = lg / 2 < 7 ? 7 : lg / 2;   // 2^15 -> 128 x 256 ; 2^17 -> 256 x 512 ; 2^20 -> 1024 x 1024 ; 2^22 -> 2048 x 2048
+    int la = lg / 2 < 7 ? 7 : lg / 2;   // 2^15 -> 128 x 256 ; 2^17 -> 256 x 512 ; 2^21 -> 1024 x 2048 ; 2^22 -> 2048 x 2048
+    // 2^20 as 512 x 2048 rather than 1024 x 1024: the A = 512 col pass fetches whole 128-byte lines (80 us per
+    // 192 MiB chunk against 97 for the 8-column tiles of A = 1024) and the M = 2048 row pass costs 68 against 56:
+    // 1.46 against 1.54 ms per 256 frames, the same in three back-to-back comparisons
+    if (lg == 20) la = 9;
     *log2a = la;
     *log2m = lg - la;
     return true;
