@@ -1013,3 +1013,15 @@ def test_scratch_placement_tuning_keeps_results_and_reports_probes(pkg):
     finally:
         lib.sdrk_dev_free(0, d_in)
         lib.sdrk_dev_free(0, d_out)
+
+
+def test_randomised_large_frame_cases(pkg):
+    """tools/stress_large.py with a fixed seed: random frame length (2^15 ... 2^22), frame count, hop, window, shift,
+    eps and epilogue against the oracle — a net under the hand-picked cases of the tiled passes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_large.py"), "14", "3"], capture_output=True,
+                       text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
