@@ -424,23 +424,75 @@ def feature_reductions(lib, _ffi, SpectrumPlan, features, dev, n_frames=1 << 18)
             lib.sdrk_dev_free(dev, b)
 
 
+def child_command(args, port):
+    """The one-rank-per-GPU launch of this file (what the driver itself runs for N > 1)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--frames", str(args.frames), "--window", args.window, "--parity-frames", str(args.parity_frames),
+           "--placement-candidates", str(args.placement_candidates), "--cpu-seconds", "0"]
+    if args.no_secondary:
+        cmd.append("--no-secondary")
+    return cmd
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) with no outer launcher: this process never touches a GPU.  It times the
+    CPU baseline (pure numpy), hands it to rank 0 through a file named in the environment, starts the ranks as a
+    CHILD process (never an exec: nothing that has initialised a GPU is ever replaced) and exits with its code;
+    the child's rank 0 prints the one JSON line on the stdout both share."""
+    import socket
+    import subprocess
+    import tempfile
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    tmp = None
+    if args.cpu_seconds > 0:
+        cpu = cpu_baseline(args.window, args.cpu_seconds)
+        if args.cpu_all_cores_seconds > 0:
+            cpu["all_cores"] = cpu_baseline_all_cores(args.window, args.cpu_all_cores_seconds)
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".json", prefix="sdrk_cpu_baseline_", delete=False)
+        json.dump(cpu, tmp)
+        tmp.close()
+        env["SDRK_BENCH_CPU_BASELINE"] = tmp.name
+    with socket.socket() as sock:                    # a free rendezvous port on the loopback
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    try:
+        rc = subprocess.call(child_command(args, port), env=env)
+    finally:
+        if tmp is not None:
+            try:
+                os.unlink(tmp.name)
+            except OSError:
+                pass
+    sys.exit(rc)
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run "
-                     "--nproc-per-node N (one rank per GPU)")
+        if "RANK" not in os.environ and args.gpus > 1:
+            self_launch(args)                        # does not return
         args.gpus = world
     solo = rank == 0 and world == 1
 
-    # cpu baseline first: plain numpy, before any GPU runtime is up (rank 0, N=1 only)
+    # cpu baseline first: plain numpy, before any GPU runtime is up.  N = 1: this process; N > 1 self-launched:
+    # the parent timed it before the ranks existed and left it in a file; N > 1 under an outer launcher: rank 0
+    # times the single-core leg while the other ranks wait at the rendezvous (they hold no CPU meanwhile).
     cpu = None
-    if solo and args.cpu_seconds > 0:
-        cpu = cpu_baseline(args.window, args.cpu_seconds)
-        if args.cpu_all_cores_seconds > 0:
+    handed = os.environ.get("SDRK_BENCH_CPU_BASELINE")
+    if rank == 0 and handed and os.path.exists(handed):
+        try:
+            cpu = json.load(open(handed))
+        except Exception:
+            cpu = None
+    elif rank == 0 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(args.window, args.cpu_seconds if solo else min(args.cpu_seconds, 5.0))
+        if solo and args.cpu_all_cores_seconds > 0:
             cpu["all_cores"] = cpu_baseline_all_cores(args.window, args.cpu_all_cores_seconds)
 
     import torch  # before libsdrk: one shared HIP runtime in the process (see _ffi.py)
@@ -456,6 +508,8 @@ def main():
     # One rank per GPU over RCCL ("nccl").  Rehearsal on a box with fewer GPUs than ranks
     # (ranks then share a device, which RCCL refuses): gloo carries the barrier/max-reduce.
     backend = "nccl" if n_dev >= world else "gloo"
+    if n_dev < world:
+        args.placement_candidates = 1               # ranks share a GPU here: no probing with its memory
     if "RANK" in os.environ:
         import torch.distributed as dist
         torch.cuda.set_device(dev)
@@ -549,6 +603,18 @@ def main():
         except Exception as e:                                   # a probe must never cost the bench line
             copy_gbps = None
             print(f"[bench] stream ceiling probe failed: {e}", file=sys.stderr)
+
+    # ... and the guide's reference shape, a 1:1 float4 copy (MI355X_MICROARCH.md: 6.29 TB/s), between the same
+    # two buffers: the first 16 GiB of the IQ buffer into the row buffer
+    copy11_gbps = None
+    if rank == 0:
+        try:
+            ms = (ctypes.c_float * 10)()
+            nbytes = frames * NFFT * 4
+            _ffi.check(lib.sdrk_copy_probe(dev, d_in, d_out, nbytes, 10, ms))
+            copy11_gbps = 2 * nbytes / (_median(list(ms)) * 1e-3) / 1e9
+        except Exception as e:
+            print(f"[bench] 1:1 copy probe failed: {e}", file=sys.stderr)
 
     # the other window of configs[1] on the same buffers (SURVEY.md §8d names Hann and rect); rank 0, N = 1 only
     other_window = None
@@ -647,6 +713,10 @@ def main():
                 "frac_of_measured_copy": None if not copy_gbps else round(achieved / copy_gbps, 4),
                 "measured_copy_what": "sdrk_stream_ceiling_probe: 32 KiB read + 16 KiB written per frame, no arithmetic, "
                                       "same buffers, median of 10 launches after the timed region",
+                "copy_1to1_GBps": None if copy11_gbps is None else round(copy11_gbps, 1),
+                "frac_of_copy_1to1": None if not copy11_gbps else round(achieved / copy11_gbps, 4),
+                "copy_1to1_what": "sdrk_copy_probe: plain 1:1 copy, 16 B per lane each way, first half of the IQ buffer into "
+                                  "the row buffer (read + written bytes / time); MI355X_MICROARCH.md quotes 6.29 TB/s for this shape",
             },
             "launch_ms": {"min": round(min(each_ms), 4), "median": round(_median(each_ms), 4),
                           "max": round(max(each_ms), 4), "mean": round(sum(each_ms) / len(each_ms), 4),

@@ -179,12 +179,16 @@ int sdrk_exec_device_timed_each(sdrk_plan* plan, const void* d_iq_c64, size_t n_
  *   shape at N = 4096 (32 KiB read + 16 KiB written per frame, no arithmetic), timed per
  *   launch on device buffers the caller provides (d_in: n*32 KiB, d_out: n*16 KiB) — the
  *   "measured-copy" ceiling SURVEY.md §8(d) asks to be reported next to the nominal 8 TB/s.
+ * sdrk_copy_probe: a plain 1:1 copy of `bytes` (16 bytes per lane each way, non-temporal) from d_in to
+ *   d_out, timed per launch — the shape MI355X_MICROARCH.md quotes 6.29 TB/s for; run on the same buffers it
+ *   anchors the 2:1 probe above to a published figure.  Bandwidth = 2 * bytes / time.
  * sdrk_host_link_probe: pinned-memory DMA rates in GB/s — `bytes` host-to-device, bytes/2
  *   device-to-host, and both at once (quoted on the upstream bytes): what the numpy
  *   boundary could reach at best.
  * sdrk_host_threads: helper threads of the host staging pool (SDRK_HOST_THREADS overrides). */
 int sdrk_stream_ceiling_probe(int device, const void* d_in, void* d_out, size_t n_frames4096,
                               int launches, float* each_ms);
+int sdrk_copy_probe(int device, const void* d_in, void* d_out, size_t bytes, int launches, float* each_ms);
 int sdrk_host_link_probe(int device, size_t bytes, double* h2d_gbps, double* d2h_gbps,
                          double* duplex_gbps);
 int sdrk_host_threads(void);

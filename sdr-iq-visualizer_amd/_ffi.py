@@ -78,6 +78,7 @@ SYMBOLS = [
     ("sdrk_exec_device_timed_each", c_int,
      [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float)]),
     ("sdrk_stream_ceiling_probe", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_float)]),
+    ("sdrk_copy_probe", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_float)]),
     ("sdrk_host_link_probe", c_int, [c_int, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     ("sdrk_host_threads", c_int, []),
     ("sdrk_synth_fill", c_int, [c_int, c_uint32, c_uint64, c_size_t, c_int, c_void_p, c_void_p]),

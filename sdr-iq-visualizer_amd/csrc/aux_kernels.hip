@@ -138,6 +138,33 @@ hipError_t launch_stream_mix(const void* d_in, void* d_out, size_t n_frames4096,
     return hipGetLastError();
 }
 
+// The guide's reference shape for "achievable HBM bandwidth": a 1:1 copy, 16 bytes per lane each way
+// (MI355X_MICROARCH.md quotes 6.29 TB/s for it).  Grid-stride over a fixed grid of 8 workgroups per CU, four
+// independent 16-byte loads per thread in flight.  bench.py runs it on the timed run's own buffers so that the
+// 2:1 probe above can be anchored to a number somebody else measured.
+__global__ __launch_bounds__(256) void copy_1to1_kernel(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n_vec) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n_vec; i += stride) {
+        v4f v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + 256 * j < n_vec) v[j] = __builtin_nontemporal_load(&in[i + 256 * j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + 256 * j < n_vec) __builtin_nontemporal_store(v[j], &out[i + 256 * j]);
+    }
+}
+
+hipError_t launch_copy_1to1(const void* d_in, void* d_out, size_t bytes, int num_cus, hipStream_t stream) {
+    const size_t n_vec = bytes / 16;
+    if (n_vec == 0) return hipSuccess;
+    size_t blocks = (n_vec + 1023) / 1024;
+    if (blocks > (size_t)num_cus * 8) blocks = (size_t)num_cus * 8;
+    hipLaunchKernelGGL(copy_1to1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const v4f*>(d_in),
+                       static_cast<v4f*>(d_out), n_vec);
+    return hipGetLastError();
+}
+
 hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,
                              hipStream_t stream) {
     hipLaunchKernelGGL(power_mean_kernel, dim3((nfft + 255) / 256), dim3(256), 0, stream,

@@ -458,6 +458,36 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
 
 }  // namespace
 
+namespace {
+// `launches` timed launches (after two untimed ones) of a probe kernel on a private stream
+template <typename Launch>
+int timed_probe(int device, int launches, float* each_ms, const char* what, Launch&& launch) {
+    int st = check_device(device);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    for (int i = -2; i < launches && e == hipSuccess; ++i) {     // two untimed warm-ups
+        if (i >= 0) e = hipEventRecord(e0, s);
+        if (e == hipSuccess) e = launch(prop.multiProcessorCount, s);
+        if (i >= 0 && e == hipSuccess) e = hipEventRecord(e1, s);
+        if (i >= 0 && e == hipSuccess) e = hipEventSynchronize(e1);
+        if (i >= 0 && e == hipSuccess) e = hipEventElapsedTime(&each_ms[i], e0, e1);
+    }
+    (void)hipStreamSynchronize(s);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    return SDRK_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int sdrk_version(void) { return SDRK_VERSION; }
@@ -995,29 +1025,17 @@ int sdrk_stream_ceiling_probe(int device, const void* d_in, void* d_out, size_t 
                               float* each_ms) {
     if (!d_in || !d_out || !each_ms || launches < 1 || launches > 4096 || n_frames4096 == 0)
         return fail(SDRK_ERR_INVALID, "bad argument");
-    int st = check_device(device);
-    if (st != SDRK_OK) return st;
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    hipStream_t s = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    hipError_t e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    for (int i = -2; i < launches && e == hipSuccess; ++i) {     // two untimed warm-ups
-        if (i >= 0) e = hipEventRecord(e0, s);
-        if (e == hipSuccess) e = sdrk::launch_stream_mix(d_in, d_out, n_frames4096, prop.multiProcessorCount, s);
-        if (i >= 0 && e == hipSuccess) e = hipEventRecord(e1, s);
-        if (i >= 0 && e == hipSuccess) e = hipEventSynchronize(e1);
-        if (i >= 0 && e == hipSuccess) e = hipEventElapsedTime(&each_ms[i], e0, e1);
-    }
-    (void)hipStreamSynchronize(s);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipStreamDestroy(s);
-    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "stream ceiling probe failed: %s", hipGetErrorString(e));
-    return SDRK_OK;
+    return timed_probe(device, launches, each_ms, "stream ceiling probe", [&](int cus, hipStream_t s) {
+        return sdrk::launch_stream_mix(d_in, d_out, n_frames4096, cus, s);
+    });
+}
+
+int sdrk_copy_probe(int device, const void* d_in, void* d_out, size_t bytes, int launches, float* each_ms) {
+    if (!d_in || !d_out || !each_ms || launches < 1 || launches > 4096 || bytes < 16)
+        return fail(SDRK_ERR_INVALID, "bad argument");
+    return timed_probe(device, launches, each_ms, "copy probe", [&](int cus, hipStream_t s) {
+        return sdrk::launch_copy_1to1(d_in, d_out, bytes, cus, s);
+    });
 }
 
 int sdrk_host_link_probe(int device, size_t bytes, double* h2d_gbps, double* d2h_gbps, double* duplex_gbps) {

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import cpu_ref
-from tests.parity import assert_db_parity, peak_rel_err
+from tests.parity import assert_db_parity, assert_db_parity_deep, peak_rel_err
 
 
 def test_oracle_matches_reference_n4096(golden):
@@ -25,6 +25,7 @@ def test_oracle_matches_reference_n4096(golden):
         got32 = cpu_ref.spectrum_db(iq)
         assert got32.dtype == np.float32
         assert peak_rel_err(got32, ref32) <= 2e-6, name
+        assert_db_parity_deep(got32, ref32, tol_db=1e-3, what=name)      # weak bins too (tests/parity.py)
         ref64 = g[f"{name}/power_db_c128"]
         got64 = cpu_ref.spectrum_db(iq.astype(np.complex128))
         assert got64.dtype == np.float64

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import cpu_ref
-from tests.parity import assert_complex_parity, assert_db_parity, peak_rel_err
+from tests.parity import assert_complex_parity, assert_db_parity, assert_db_parity_deep, peak_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +44,24 @@ def test_golden_n4096_against_reference_outputs(pkg, golden):
         assert_db_parity(got, g[f"{name}/power_db_c128"].astype(np.float32), what=f"{name} vs reference(c128)")
 
 
+def test_golden_n4096_weak_bins_in_db(pkg, golden):
+    """streamer.py:121 on WEAK bins: every bin within 70 dB of its frame's peak to 0.01 dB against the rows the
+    reference produced (the second tone of two_tones_60db, the leakage skirt of the off-bin tone, the noise under
+    tone_plus_pluto_noise) — the peak-relative bound above holds those only to ~1 % of their own magnitude."""
+    g = golden["ref_n4096"]
+    worst = {}
+    for name in (str(n) for n in g["names"]):
+        got = pkg.spectrum_db(g[f"{name}/iq"])
+        worst[name] = max(assert_db_parity_deep(got, g[f"{name}/power_db_c64"], what=f"{name} vs reference(c64)"),
+                          assert_db_parity_deep(got, g[f"{name}/power_db_c128"], what=f"{name} vs reference(c128)"))
+        if name in ("two_tones_60db", "tone_offbin_k100p37", "tone_plus_pluto_noise"):
+            hann = pkg.spectrum_db(g[f"{name}/iq"], window="hann")
+            assert_db_parity_deep(hann, cpu_ref.spectrum_db(g[f"{name}/iq"], window=np.hanning(4096)), what=f"{name} hann vs oracle")
+    print("max |delta dB| within 70 dB of the peak:", {k: f"{v:.2e}" for k, v in worst.items()})
+    two = g["two_tones_60db/power_db_c64"].astype(np.float64)
+    assert np.sum(two >= two.max() - 70.0) >= 2          # the weak tone is inside the checked range
+
+
 def test_golden_exact_structure(pkg, golden):
     g = golden["ref_n4096"]
     z = pkg.spectrum_db(g["zeros/iq"])
@@ -76,6 +94,8 @@ def test_golden_large_frames_sampled_bins(pkg, golden, n):
     scale = 10 ** (float(ref.max()) / 20)
     err = np.abs(10 ** (p[idx].astype(np.float64) / 20) - 10 ** (ref.astype(np.float64) / 20)).max() / scale
     assert err <= 1e-5, err
+    # the sampled bins in dB, weak ones included (noise bins sit 50-60 dB under the tone)
+    assert_db_parity_deep(np.append(p[idx], p.max()), np.append(ref, ref.max()), what=f"n={n} sampled bins vs reference")
     assert int(np.argmax(p)) == int(g[f"n{n}/argmax"][0])
     assert abs(float(np.sum(p.astype(np.float64))) - float(g[f"n{n}/sum_db"][0])) <= 2e-5 * n
     assert_db_parity(p, cpu_ref.spectrum_db(x), what=f"n={n} full row vs oracle")
