@@ -5,63 +5,57 @@
 // that needs the ~20 scalars and the peak list per frame costs 8 B/sample of HBM traffic (the IQ read)
 // instead of 8 + 4 (row written) + 4 (row read back by a separate reduction kernel).
 //
-// Same decomposition, LDS layouts and software pipeline as fft4096.hip (kept as a separate kernel so that
-// the flagship's register allocation is untouched); after the last pass the 16 KiB row replaces the
-// exchange buffer in LDS, followed by the reduction scratch.
+// Same decomposition and LDS layouts as fft4096.hip, but a different balance: the reductions, not the HBM stream,
+// bound this kernel (~8x the transform's instruction count, most of it latency-bound hand-offs between the four
+// waves), so it is built for occupancy instead of for bytes in flight — no register prefetch of the next frame
+// (32 VGPRs) and the window read from L2 instead of a 16 KiB LDS copy: <= 128 VGPRs and 37 KiB of LDS, FOUR
+// workgroups per CU that fill each other's barrier waits (the flagship runs three).  After the last pass the
+// 16 KiB row replaces the exchange buffer in LDS, followed by the reduction scratch.
 #include "fft4096_core.h"
 #include "row_features_core.h"
 
 namespace sdrk {
 
+#ifndef F4KF_WAVES
+#define F4KF_WAVES 4   // workgroups per CU = waves per SIMD
+#endif
+
 template <bool HAS_WINDOW>
-__global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_features_kernel(
+__global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kernel(
     const float2* __restrict__ iq, size_t frame_stride, float* __restrict__ out_db, size_t n_frames,
     const float* __restrict__ window, const float2* __restrict__ tw4096, float eps, int shift, RowFeatParams prm,
     double* __restrict__ stats, double* __restrict__ thr, int* __restrict__ idx, int* __restrict__ cnt) {
-    __shared__ float2 lds[F4K_XCH_ELEMS + F4K_TW_ELEMS + (HAS_WINDOW ? F4K_N / 2 : 0)];
+    __shared__ float2 lds[F4K_XCH_ELEMS + F4K_TW_ELEMS];
     static_assert(F4K_XCH_ELEMS * sizeof(float2) >= F4K_N * sizeof(float) + sizeof(RowFeatShared) + 16,
                   "row + reduction scratch must fit the exchange buffer");
     float2* __restrict__ tw256 = lds + F4K_XCH_ELEMS;
     float2* __restrict__ tw4k = tw256 + 256;
-    float* __restrict__ lds_win = reinterpret_cast<float*>(tw4k + 256);
     float* __restrict__ row = reinterpret_cast<float*>(lds);                                  // 4096 float32
     RowFeatShared& sh = *reinterpret_cast<RowFeatShared*>(reinterpret_cast<char*>(lds) + F4K_N * sizeof(float));
 
     const int tid = threadIdx.x;
     F4kAddr A = f4k_addr(tid);
     f4k_init_tables(tw256, tw4k, tw4096, tid, A);
-    if (HAS_WINDOW) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) lds_win[tid + 256 * j] = window[tid + 256 * j];
-    }
     __syncthreads();
 
     const int xor_k2 = shift ? 8 : 0;
-    const int voff_in = tid * 8;
-    const size_t first = blockIdx.x, step = gridDim.x;
-    v2u nxt[16];
-    {
-        __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + first * frame_stride, F4K_N * 8);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, 2);
-    }
-    for (size_t f = first; f < n_frames; f += step) {
+    const __amdgpu_buffer_rsrc_t rwin = frame_rsrc(window, HAS_WINDOW ? F4K_N * 4 : 0);
+    for (size_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
         cf v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            v2f t = __builtin_bit_cast(v2f, nxt[j]);
-            v[j] = cf{t.x, t.y};
-        }
         {
-            size_t fn = f + step;
-            if (fn >= n_frames) fn = f;  // harmless re-read on the last trip
-            __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + fn * frame_stride, F4K_N * 8);
+            const __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + f * frame_stride, F4K_N * 8);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff_in, j * 2048, 2);
-        }
-        if (HAS_WINDOW) {
+            for (int j = 0; j < 16; ++j) {
+                const v2f t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, j * 2048, 2));
+                v[j] = cf{t.x, t.y};
+            }
+            if (HAS_WINDOW) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = v[j] * lds_win[tid + 256 * j];
+                for (int j = 0; j < 16; ++j) {
+                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwin, tid * 4, j * 1024, 0));
+                    v[j] = v[j] * w;
+                }
+            }
         }
         f4k_transform(v, lds, tw256, tw4k, A, tid);
         __syncthreads();   // every thread is through its last exchange read: the buffer becomes the row
@@ -86,7 +80,7 @@ hipError_t launch_fft4096_features(const LaunchArgs& a, int rank, float gamma, i
     if (a.n_frames == 0) return hipSuccess;
     if (a.nfft != F4K_N) return hipErrorInvalidValue;
     RowFeatParams prm{rank, gamma, min_distance, max_peaks};
-    const size_t max_blocks = (size_t)a.num_cus * F4K_WAVES;
+    const size_t max_blocks = (size_t)a.num_cus * F4KF_WAVES;
     const unsigned grid = (unsigned)(a.n_frames < max_blocks ? a.n_frames : max_blocks);
     const float2* iq = static_cast<const float2*>(a.d_iq);
     const float2* tw = static_cast<const float2*>(a.d_twiddle);

@@ -622,7 +622,7 @@ static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, u
     }
 }
 
-hipError_t launch_fft_tiled2(const LaunchArgs& a) {
+static hipError_t launch_fft_tiled2_serial(const LaunchArgs& a) {
     if (a.n_frames == 0) return hipSuccess;
     int la = 0, lm = 0;
     if (!fft_tiled2_split(a.nfft, &la, &lm)) return hipErrorInvalidValue;
@@ -679,6 +679,97 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// One chunk's col pass / row pass (the kernels are chosen by the split alone).
+static hipError_t col_pass(const LaunchArgs& a, int la, const float2* src, size_t nf, int M, unsigned grid_cap, unsigned grid_cap_1024) {
+    switch (la) {
+        case 7: return launch_col<7>(a, src, nf, M, grid_cap);
+        case 8: return launch_col<8>(a, src, nf, M, grid_cap);
+        case 9: return launch_col<9>(a, src, nf, M, grid_cap);
+        case 10: return launch_col<10>(a, src, nf, M, grid_cap);
+        default: return launch_col<11>(a, src, nf, M, grid_cap_1024);
+    }
+}
+static hipError_t row_pass(const LaunchArgs& a, int lm, void* dst, size_t nf, int A, unsigned grid_cap, unsigned grid_cap_1024) {
+    switch (lm) {
+        case 8: return launch_row<8>(a, dst, nf, A, grid_cap);
+        case 9: return launch_row<9>(a, dst, nf, A, grid_cap);
+        case 10: return launch_row<10>(a, dst, nf, A, grid_cap);
+        default: return launch_row<11>(a, dst, nf, A, grid_cap_1024);
+    }
+}
+
+hipError_t launch_fft_tiled2(const LaunchArgs& a) {
+    if (a.n_frames == 0) return hipSuccess;
+    int la = 0, lm = 0;
+    if (!fft_tiled2_split(a.nfft, &la, &lm)) return hipErrorInvalidValue;
+    const int A = 1 << la, M = 1 << lm;
+    const float2* iq = static_cast<const float2*>(a.d_iq);
+    const size_t out_elem = a.epilogue == EPI_LOGPSD ? sizeof(float) : sizeof(float2);
+    // Overlapped form: two role-sized grids resident together, two scratch halves.  Needs the second stream and
+    // its events, and at least three half-chunks of work (otherwise nothing overlaps).
+    const bool want_ovl = a.stream2 && a.ev_fork && a.col_cus > 0 && a.row_cus > 0;
+    const int ccus = want_ovl ? a.col_cus : a.num_cus, rcus = want_ovl ? a.row_cus : a.num_cus;
+    // workgroups per CU: LDS 136 B per point of A (or M); at most 2048 threads
+    auto cap = [&](int L, int cus) {
+        size_t per_cu = (160 * 1024) / ((size_t)136 * L);
+        const size_t by_threads = 2048 / L;
+        if (per_cu > by_threads) per_cu = by_threads;
+        if (per_cu > 4) per_cu = 4;
+        if (per_cu < 1) per_cu = 1;
+        return (unsigned)(cus * per_cu);
+    };
+    // Frames per chunk: the scratch capacity, rounded down to a whole number of grid passes of BOTH kernels
+    // (col: 3 workgroups per CU when software-pipelined, else cap(A); row: cap(M)) so that no persistent
+    // workgroup gets one work item more than its neighbours (N = 65536: 256 frames = 5.33 col items per
+    // workgroup became 192 = exactly 4 col and 3 row items).
+    auto round_chunk = [&](size_t chunk) {
+        auto gcd = [](size_t x, size_t y) { while (y) { size_t t = x % y; x = y; y = t; } return x; };
+        const int Wc = COL_TILE_W(la <= 11 ? la : 11), Rr = 16;
+        const bool pipelined = (A / 16) * Wc <= 256 && Wc >= 16;
+        size_t col_grid = STAGED_W(la) ? (size_t)ccus
+                        : (Wc == 8 ? (size_t)ccus * 2 : (pipelined ? (size_t)ccus * 3 : cap(A < 1024 ? A : 1024, ccus)));
+        if (pipelined && col_grid > cap(A, ccus)) col_grid = cap(A, ccus);
+        const size_t row_grid = M >= 2048 ? (size_t)rcus : (M == 1024 ? (size_t)rcus * 2 : cap(M, rcus));
+        size_t cw = col_grid / (size_t)(M / Wc), rw = row_grid / (size_t)(A / Rr);
+        if (cw < 1) cw = 1;
+        if (rw < 1) rw = 1;
+        const size_t l = cw / gcd(cw, rw) * rw;
+        if (chunk >= l) chunk -= chunk % l;
+        return chunk;
+    };
+    LaunchArgs ca = a, ra = a;
+    ca.num_cus = ccus;
+    ra.num_cus = rcus;
+    const size_t half = round_chunk(a.scratch_frames / 2);
+    if (want_ovl && half >= 1 && a.n_frames > 2 * half) {
+        // col(i) on `stream` into scratch half i % 2; row(i) on `stream2` out of it, beside col(i + 1).  ev_col[h]:
+        // half h written; ev_row[h]: half h read (free for col(i + 2)).  Everything is joined back into `stream`
+        // at the end, so the caller's stream order (and its timing events) cover the whole transform.
+        ra.stream = a.stream2;
+        hipError_t e = hipEventRecord(a.ev_fork, a.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(a.stream2, a.ev_fork, 0);
+        if (e != hipSuccess) return e;
+        size_t i = 0;
+        for (size_t f0 = 0; f0 < a.n_frames; f0 += half, ++i) {
+            const size_t nf = (a.n_frames - f0 < half) ? a.n_frames - f0 : half;
+            const int h = (int)(i & 1);
+            ca.d_scratch = ra.d_scratch = static_cast<float2*>(a.d_scratch) + (size_t)h * half * (size_t)a.nfft;
+            if (i >= 2 && (e = hipStreamWaitEvent(a.stream, a.ev_row[h], 0)) != hipSuccess) return e;
+            e = col_pass(ca, la, iq + f0 * a.frame_stride, nf, M, cap(A, ccus), cap(1024, ccus));
+            if (e == hipSuccess) e = hipEventRecord(a.ev_col[h], a.stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(a.stream2, a.ev_col[h], 0);
+            if (e != hipSuccess) return e;
+            e = row_pass(ra, lm, static_cast<char*>(a.d_out) + f0 * (size_t)a.nfft * out_elem, nf, A, cap(M, rcus), cap(1024, rcus));
+            if (e == hipSuccess) e = hipEventRecord(a.ev_row[h], a.stream2);
+            if (e != hipSuccess) return e;
+        }
+        e = hipStreamWaitEvent(a.stream, a.ev_row[0], 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(a.stream, a.ev_row[1], 0);
+        return e;
+    }
+    return launch_fft_tiled2_serial(a);   // one stream, whole-device grids, the whole scratch per chunk
 }
 
 }  // namespace sdrk

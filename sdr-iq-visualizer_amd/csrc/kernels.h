@@ -30,6 +30,12 @@ struct LaunchArgs {
     void* d_scratch = nullptr;         // large-N plans: complex64 scratch, scratch_frames*nfft
     size_t scratch_frames = 0;
     const void* d_twiddle_2p = nullptr;   // two-pass tiled plans: W_A[2048] W_M[2048] t1T[(A/16)*M] t2[M*16]
+    // two-pass tiled plans, overlapped form (fft_tiled2.hip): the row pass of chunk i runs on `stream2` beside the
+    // col pass of chunk i+1 on `stream`, each on its own half of the scratch; col_cus / row_cus size the two
+    // persistent grids so that both kernels are resident together (0: num_cus)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_col[2] = {nullptr, nullptr}, ev_row[2] = {nullptr, nullptr}, ev_fork = nullptr;
+    int col_cus = 0, row_cus = 0;
 };
 
 // 20*log10(sqrt(re^2+im^2) + eps), the expression order of streamer.py:121:

@@ -17,10 +17,13 @@
 
 namespace sdrk {
 
+#ifndef RF_MIN_WAVES
+#define RF_MIN_WAVES 3   // workgroups per SIMD the register allocation aims at
+#endif
 constexpr int RF_STAGE_MAX = 32768;   // bins: 128 KiB of the 160 KiB LDS
 
 template <bool STAGE>
-__global__ __launch_bounds__(RF_THREADS) void row_features_kernel(const float* __restrict__ rows, size_t n_rows, int nfft,
+__global__ __launch_bounds__(RF_THREADS, RF_MIN_WAVES) void row_features_kernel(const float* __restrict__ rows, size_t n_rows, int nfft,
                                                                  RowFeatParams prm, double* __restrict__ stats,
                                                                  double* __restrict__ thr, int* __restrict__ idx,
                                                                  int* __restrict__ cnt) {

@@ -15,26 +15,46 @@
 //   peaks: strict local maxima above thr, accepted left to right when >= min_distance bins after the
 //     previously accepted one (:200-212)
 //
-// Order statistics: exact radix select on the float32 keys, 8 bits per pass (no sort); the second one
-// (rank+1) costs one more pass: it equals sorted[rank] when more than rank+1 elements are <= it, else it
-// is the smallest larger element.
+// Order statistics, rows of up to 4096 bins (the reference's frame length): the 16 values of a thread stay in
+// registers for every scan, and the two order statistics come from ONE histogram pass — 2048 bins of 1/16 dB
+// around the row's mean (a monotone float32 map, so bin order is value order), a 256-thread prefix scan to the
+// bins that hold ranks r and r+1, and an exact ranking of the handful of values inside them (<= 64, else the
+// radix select below takes over, as it does for rows with NaN / inf values or a percentile more than 64 dB off
+// the mean).  Longer rows: exact radix select on the float32 keys, 8 bits per pass (no sort); the second
+// statistic (rank+1) costs one more pass: it equals sorted[rank] when more than rank+1 elements are <= it, else
+// it is the smallest larger element.
+//
+// Sums: mean, variance and fourth moment in float64 exactly as before.  mean p: 10^(x/10) per bin as float32
+// v_exp_f32 on an exactly reduced argument (relative error ~1e-7 per term, random sign), accumulated in float64;
+// mean ln p = (ln10/10) * mean x needs no transcendental.  (BASELINE.json asks for 1e-5; the float64 degree-10
+// polynomial this replaces held 1e-11 at ~6x the cost.)
 #pragma once
 #include "kernels.h"
 
 namespace sdrk {
 
 constexpr int RF_THREADS = 256;
+constexpr int RF_BINS = 2048;          // histogram select: bins of 1/RF_BINS_PER_DB dB, window [mean - 64, mean + 64) dB
+constexpr float RF_BINS_PER_DB = 16.0f;
+constexpr int RF_CAND = 64;            // values ranked exactly inside the target bins
 
 struct RowFeatShared {
     double d[4 * 3];
+    double d2[4 * 2];
     float f[4];
-    int i[4 * 7];
+    int i[4 * 8];                   // [0,4) argmax per wave, [4,28) band edges per wave, [28,32) clipped-bin counts
     unsigned hist[256];
     unsigned state[4];
     unsigned long long flags[64];   // candidate bits of one 4096-bin stretch of the row
     int pk[2];
     int list[64];                   // accepted peak indices waiting for one coalesced store
     double thr;
+    // histogram select of rows held in registers (n <= 16 * RF_THREADS)
+    alignas(16) unsigned bins[RF_BINS];
+    unsigned wtot[4];
+    int sel[4];                     // bin of rank r, bin of rank r+1, values below the first bin, candidates collected
+    float cand[RF_CAND];
+    unsigned long long tbl[64];     // peak scan of short rows: exit state of every 64-bin word for every entry state
 };
 
 struct RowFeatParams {
@@ -80,6 +100,20 @@ __device__ __forceinline__ double rf_pow10_tenth(double v) {
     return ldexp(p, (int)kk);
 }
 
+// 10^(v/10) in float32: t = v log2(10)/10 = k + f with k = rint(t) and f formed by two fmas (the second one
+// carries the low part of the constant, so f is exact to ~1e-9), 2^f by v_exp_f32 (1 ulp), scaled by v_ldexp_f32.
+// v = -inf gives 0; NaN stays NaN.
+__device__ __forceinline__ float rf_pow10_tenth_f32(float v) {
+    const float C_HI = 0.33219280948873623479f;                    // float32(log2(10) / 10)
+    const float C_LO = (float)(0.33219280948873623479 - (double)C_HI);
+    const float k = rintf(v * C_HI);
+    float f = fmaf(v, C_HI, -k);
+    f = fmaf(v, C_LO, f);
+    const float kk = fminf(fmaxf(k, -300.0f), 300.0f);
+    const float p = ldexpf(__builtin_amdgcn_exp2f(f), (int)kk);
+    return v == -INFINITY ? 0.0f : p;
+}
+
 // k-th smallest (0-based) of x[0..n) and the (k+1)-th: q0, q1 (q1 == q0 when k == n-1).
 // Exact radix select, 8 bits per pass.  Two things keep a pass short: (1) dB rows share their sign and high
 // exponent bits, so in the top-byte pass nearly every key lands in the same 1-3 bins — that pass counts equal
@@ -87,19 +121,8 @@ __device__ __forceinline__ double rf_pow10_tenth(double v) {
 // serialised same-address ones (the lower bytes are spread and use plain atomics); (2) the digit that holds the wanted rank is found by a 256-thread prefix
 // scan over the histogram, not by one thread walking 256 LDS words.
 template <class RowPtr>
-__device__ __forceinline__ void rf_select_pair(RowPtr x, int n, unsigned rank, RowFeatShared& sh, float& q0, float& q1) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // rows of up to 4096 bins (the reference's frame length): the 16 keys of a thread stay in registers for all
-    // passes; 0 is the key of no float (-NaN with every payload bit set aside), used for the slots past n
-    const bool cached = n <= 16 * RF_THREADS;
-    unsigned kreg[16];
-    if (cached) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int i = tid + RF_THREADS * j;
-            kreg[j] = i < n ? rf_key(x[i]) : 0u;
-        }
-    }
+__device__ __forceinline__ void rf_select_pair(RowPtr x, int n, unsigned rank, RowFeatShared& sh, float& q0, float& q1, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     unsigned prefix = 0, mask = 0, want = rank;
     for (int shift = 24; shift >= 0; shift -= 8) {
         __syncthreads();
@@ -121,14 +144,9 @@ __device__ __forceinline__ void rf_select_pair(RowPtr x, int n, unsigned rank, R
                 atomicAdd(&sh.hist[bin], 1u);
             }
         };
-        if (cached) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) count_key(kreg[j], tid + RF_THREADS * j < n);
-        } else {
-            for (int i0 = 0; i0 < n; i0 += RF_THREADS) {
-                const int i = i0 + tid;
-                count_key(i < n ? rf_key(x[i]) : 0u, i < n);
-            }
+        for (int i0 = 0; i0 < n; i0 += RF_THREADS) {
+            const int i = i0 + tid;
+            count_key(i < n ? rf_key(x[i]) : 0u, i < n);
         }
         __syncthreads();
         // inclusive scan of the 256 bins: thread t owns bin t
@@ -156,20 +174,10 @@ __device__ __forceinline__ void rf_select_pair(RowPtr x, int n, unsigned rank, R
     }
     // one more scan: how many keys are <= prefix, and the smallest key above it
     unsigned le = 0, next = 0xFFFFFFFFu;
-    if (cached) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (tid + RF_THREADS * j < n) {
-                if (kreg[j] <= prefix) ++le;
-                else next = kreg[j] < next ? kreg[j] : next;
-            }
-        }
-    } else {
-        for (int i = tid; i < n; i += RF_THREADS) {
-            const unsigned k = rf_key(x[i]);
-            if (k <= prefix) ++le;
-            else next = k < next ? k : next;
-        }
+    for (int i = tid; i < n; i += RF_THREADS) {
+        const unsigned k = rf_key(x[i]);
+        if (k <= prefix) ++le;
+        else next = k < next ? k : next;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -188,14 +196,94 @@ __device__ __forceinline__ void rf_select_pair(RowPtr x, int n, unsigned rank, R
     __syncthreads();
 }
 
-// The whole measurement of one row by one 256-thread workgroup.  `x` points at n float32 values (LDS or global).
-// o_stats: 16 doubles; o_thr: 1 double; o_idx: max_peaks ints; o_cnt: 1 int (total peaks found, may exceed max_peaks).
-// o_idx / o_cnt / o_thr may be null (stats only).
+// Wave-wide inclusive scans / reductions by DPP (gfx9 row shifts and row broadcasts: no LDS crossbar, no lane
+// address registers).  After the six steps lane i holds the combination of lanes 0..i; lane 63 the wave's total.
+//   row_shr:1,2,4,8 (0x111..0x118) inside each row of 16, row_bcast:15 (0x142) into rows 1 and 3, row_bcast:31
+//   (0x143) into rows 2 and 3.  Lanes without a source keep `identity`.
+#define RF_DPP_STEPS(STEP) STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+__device__ __forceinline__ unsigned rf_wave_scan_add(unsigned v) {
+#define RF_STEP(CTRL, ROWS) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false);
+    RF_DPP_STEPS(RF_STEP)
+#undef RF_STEP
+    return v;
+}
+__device__ __forceinline__ double rf_wave_scan_add(double v) {
+#define RF_STEP(CTRL, ROWS)                                                                                   \
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false),          \
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false));
+    RF_DPP_STEPS(RF_STEP)
+#undef RF_STEP
+    return v;
+}
+// (value, index) with "larger value, then smaller index" wins: lane 63 ends up with the wave's max and its first index
+__device__ __forceinline__ void rf_wave_scan_argmax(float& mx, int& amx) {
+#define RF_STEP(CTRL, ROWS)                                                                                   \
+    {                                                                                                         \
+        const float om = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000, __builtin_bit_cast(int, mx), CTRL, ROWS, 0xf, false)); \
+        const int oi = __builtin_amdgcn_update_dpp(0x7fffffff, amx, CTRL, ROWS, 0xf, false);                  \
+        if (om > mx || (om == mx && oi < amx)) { mx = om; amx = oi; }                                         \
+    }
+    RF_DPP_STEPS(RF_STEP)
+#undef RF_STEP
+}
+__device__ __forceinline__ double rf_lane63(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// Redefine sixteen registers as far as the compiler can tell (no instruction): values derived from them earlier
+// are recomputed where they are needed again instead of being kept alive across a phase.
+__device__ __forceinline__ void rf_opaque(float (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(v[j]));
+}
+
+// Everything scans A / B and the select produced, for the common tail.
+struct RowFeatValues {
+    float mx, q0, q1;
+    int amx;
+    double mean, m2, m4, mean_lp, mean_p;
+    int f3, l3, f10, l10, f20, l20;
+};
+
+// tail shared by both row sizes: thread 0 writes stats[] and forms the adaptive threshold; returns after a barrier
+__device__ __forceinline__ void rf_finish(const RowFeatValues& r, int n, const RowFeatParams& prm, RowFeatShared& sh,
+                                          double* __restrict__ o_stats, double* __restrict__ o_thr, int tid) {
+    if (tid == 0) {
+        double* o = o_stats;
+        o[0] = r.mx; o[1] = r.q0; o[2] = r.q1; o[3] = r.mean; o[4] = r.m2; o[5] = r.m4; o[6] = r.mean_lp; o[7] = r.mean_p;
+        o[8] = r.f3; o[9] = r.l3; o[10] = r.f10; o[11] = r.l10; o[12] = r.f20; o[13] = r.l20; o[14] = r.amx; o[15] = n;
+        // numpy.percentile on a float32 row: a + (b-a)*gamma, or b - (b-a)*(1-gamma) when gamma >= 0.5, every
+        // operation rounded to float32 (no contraction); then classifier.py:46,55 with NEP-50 promotion:
+        // snr = float32(max - nf) widened; second = (max - float32(0.9*snr)) + 5 in float32; first = nf + 5 in
+        // float64; python max(first, second) compares second > float32(first).
+        const float diff = __fsub_rn(r.q1, r.q0);
+        float nf = __fadd_rn(r.q0, __fmul_rn(diff, prm.gamma));
+        if (prm.gamma >= 0.5f) nf = __fsub_rn(r.q1, __fmul_rn(diff, __fsub_rn(1.0f, prm.gamma)));
+        const double snr = (double)__fsub_rn(r.mx, nf);
+        const float second = __fadd_rn(__fsub_rn(r.mx, (float)(0.9 * snr)), 5.0f);
+        const double first = (double)nf + 5.0;
+        sh.thr = second > (float)first ? (double)second : first;
+        if (o_thr) *o_thr = sh.thr;
+        sh.pk[0] = -prm.min_distance;
+        sh.pk[1] = 0;
+    }
+    __syncthreads();
+}
+
 template <class RowPtr>
-__device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatParams& prm, RowFeatShared& sh,
-                                                double* __restrict__ o_stats, double* __restrict__ o_thr,
-                                                int* __restrict__ o_idx, int* __restrict__ o_cnt) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void rf_peaks(RowPtr x, int n, const RowFeatParams& prm, RowFeatShared& sh,
+                                         int* __restrict__ o_idx, int* __restrict__ o_cnt, int tid);
+template <class RowPtr>
+__device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, int n, const RowFeatParams& prm,
+                                               RowFeatShared& sh, int* __restrict__ o_idx, int* __restrict__ o_cnt, int tid);
+
+// Rows longer than 16 values per thread: every scan reads the row where it is (LDS when staged, else L2 / HBM).
+template <class RowPtr>
+__device__ __forceinline__ void rf_large(RowPtr x, int n, const RowFeatParams& prm, RowFeatShared& sh,
+                                         double* __restrict__ o_stats, double* __restrict__ o_thr,
+                                         int* __restrict__ o_idx, int* __restrict__ o_cnt, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    RowFeatValues r;
 
     // scan A: max (+ first argmax), sums for mean and flatness
     float mx = -INFINITY;
@@ -205,7 +293,7 @@ __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatPa
         const float v = x[i];
         if (v > mx) { mx = v; amx = i; }
         sx += (double)v;
-        double p = v == -INFINITY ? 0.0 : rf_pow10_tenth((double)v);   // a row computed with eps = 0 can hold -inf
+        double p = (double)rf_pow10_tenth_f32(v);                       // a row computed with eps = 0 can hold -inf -> 0
         double lp = (double)v * 0.23025850929940456840;      // ln(10) / 10
         if (p < 1e-15) { p = 1e-15; lp = -34.538776394910684; }       // np.clip(p, 1e-15, None), then log (NaN stays NaN)
         sp += p;
@@ -228,8 +316,8 @@ __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatPa
     for (int w = 1; w < 4; ++w)
         if (sh.f[w] > mx || (sh.f[w] == mx && sh.i[w] < amx)) { mx = sh.f[w]; amx = sh.i[w]; }
     const double mean = (sh.d[0] + sh.d[3] + sh.d[6] + sh.d[9]) / n;
-    const double mean_p = (sh.d[1] + sh.d[4] + sh.d[7] + sh.d[10]) / n;
-    const double mean_lp = (sh.d[2] + sh.d[5] + sh.d[8] + sh.d[11]) / n;
+    r.mean_p = (sh.d[1] + sh.d[4] + sh.d[7] + sh.d[10]) / n;
+    r.mean_lp = (sh.d[2] + sh.d[5] + sh.d[8] + sh.d[11]) / n;
 
     // scan B: central moments, occupied-band edges (thresholds in float32, as peak - float(drop) is)
     const float t3 = mx - 3.0f, t10 = mx - 10.0f, t20 = mx - 20.0f;
@@ -252,11 +340,10 @@ __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatPa
         f10 = min(f10, __shfl_down(f10, off, 64)); l10 = max(l10, __shfl_down(l10, off, 64));
         f20 = min(f20, __shfl_down(f20, off, 64)); l20 = max(l20, __shfl_down(l20, off, 64));
     }
-    __syncthreads();
     if (lane == 0) {
         int* s = sh.i + 4 + wave * 6;
         s[0] = f3; s[1] = l3; s[2] = f10; s[3] = l10; s[4] = f20; s[5] = l20;
-        sh.d[wave * 3] = s2; sh.d[wave * 3 + 1] = s4;
+        sh.d2[wave * 2] = s2; sh.d2[wave * 2 + 1] = s4;
     }
     __syncthreads();
     for (int w = 0; w < 4; ++w) {
@@ -264,36 +351,355 @@ __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatPa
         f3 = min(f3, s[0]); l3 = max(l3, s[1]); f10 = min(f10, s[2]); l10 = max(l10, s[3]);
         f20 = min(f20, s[4]); l20 = max(l20, s[5]);
     }
-    const double m2 = (sh.d[0] + sh.d[3] + sh.d[6] + sh.d[9]) / n;
-    const double m4 = (sh.d[1] + sh.d[4] + sh.d[7] + sh.d[10]) / n;
+    r.m2 = (sh.d2[0] + sh.d2[2] + sh.d2[4] + sh.d2[6]) / n;
+    r.m4 = (sh.d2[1] + sh.d2[3] + sh.d2[5] + sh.d2[7]) / n;
+    r.mx = mx; r.amx = amx; r.mean = mean;
+    r.f3 = f3; r.l3 = l3; r.f10 = f10; r.l10 = l10; r.f20 = f20; r.l20 = l20;
 
     // order statistics for numpy.percentile's linear interpolation
     const int r0 = prm.rank < 0 ? 0 : (prm.rank > n - 1 ? n - 1 : prm.rank);
-    float q0, q1;
-    rf_select_pair(x, n, (unsigned)r0, sh, q0, q1);
+    rf_select_pair(x, n, (unsigned)r0, sh, r.q0, r.q1, tid);
+    rf_finish(r, n, prm, sh, o_stats, o_thr, tid);
+    if (o_idx && o_cnt) rf_peaks(x, n, prm, sh, o_idx, o_cnt, tid);
+}
 
-    if (tid == 0) {
-        double* o = o_stats;
-        o[0] = mx; o[1] = q0; o[2] = q1; o[3] = mean; o[4] = m2; o[5] = m4; o[6] = mean_lp; o[7] = mean_p;
-        o[8] = f3; o[9] = l3; o[10] = f10; o[11] = l10; o[12] = f20; o[13] = l20; o[14] = amx; o[15] = n;
-        // numpy.percentile on a float32 row: a + (b-a)*gamma, or b - (b-a)*(1-gamma) when gamma >= 0.5, every
-        // operation rounded to float32 (no contraction); then classifier.py:46,55 with NEP-50 promotion:
-        // snr = float32(max - nf) widened; second = (max - float32(0.9*snr)) + 5 in float32; first = nf + 5 in
-        // float64; python max(first, second) compares second > float32(first).
-        const float diff = __fsub_rn(q1, q0);
-        float nf = __fadd_rn(q0, __fmul_rn(diff, prm.gamma));
-        if (prm.gamma >= 0.5f) nf = __fsub_rn(q1, __fmul_rn(diff, __fsub_rn(1.0f, prm.gamma)));
-        const double snr = (double)__fsub_rn(mx, nf);
-        const float second = __fadd_rn(__fsub_rn(mx, (float)(0.9 * snr)), 5.0f);
-        const double first = (double)nf + 5.0;
-        sh.thr = second > (float)first ? (double)second : first;
-        if (o_thr) *o_thr = sh.thr;
-        sh.pk[0] = -prm.min_distance;
-        sh.pk[1] = 0;
+// Rows of up to 16 values per thread (n <= 4096: the reference's frame length and below): the row is read once
+// more into registers, and nothing after that reads it again except the neighbour compares of the peak scan.
+template <class RowPtr>
+__device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& prm, RowFeatShared& sh,
+                                         double* __restrict__ o_stats, double* __restrict__ o_thr,
+                                         int* __restrict__ o_idx, int* __restrict__ o_cnt, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RowFeatValues r;
+    float xv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = tid + RF_THREADS * j;
+        xv[j] = i < n ? x[i] : 0.0f;
+    }
+    {   // histogram of the select: thread t owns bins 8t .. 8t+7 here and in the prefix scan
+        typedef unsigned rf_v4u __attribute__((ext_vector_type(4)));
+        rf_v4u* b4 = reinterpret_cast<rf_v4u*>(sh.bins);
+        const rf_v4u z = {0u, 0u, 0u, 0u};
+        b4[2 * tid] = z;
+        b4[2 * tid + 1] = z;
+        if (tid == 0) sh.sel[3] = 0;
+    }
+
+    // scan A: max (+ first argmax), sum of x, sum of p = max(10^(x/10), 1e-15), sum of the unclipped x (for mean ln p).
+    // Bins under -150 dB are clipped by np.clip(p, 1e-15, None); a wave that holds none (every wave of an ordinary row)
+    // takes the loop without the clip selects: su = sum of all its x, sc = 0.
+    float mx = -INFINITY;
+    int amx = 0x7fffffff, nclip = 0;
+    double su = 0.0, sc = 0.0, sp = 0.0;      // unclipped x, clipped x, p
+    float vmin = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) vmin = fminf(vmin, tid + RF_THREADS * j < n ? xv[j] : INFINITY);
+    const bool careful = __any(!(vmin > -149.0f));
+    if (!careful) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = tid + RF_THREADS * j;
+            if (i < n) {
+                const float v = xv[j];
+                if (v > mx) { mx = v; amx = i; }
+                su += (double)v;
+                sp += (double)rf_pow10_tenth_f32(v);
+            }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four elements in flight at a time (register pressure)
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = tid + RF_THREADS * j;
+            if (i < n) {
+                const float v = xv[j];
+                if (v > mx) { mx = v; amx = i; }
+                const double dv = (double)v;
+                const float p = rf_pow10_tenth_f32(v);
+                const bool clip = p < 1e-15f;                 // np.clip(p, 1e-15, None) (NaN stays NaN)
+                sp += clip ? 1e-15 : (double)p;
+                su += clip ? 0.0 : dv;
+                sc += clip ? dv : 0.0;
+                nclip += clip ? 1 : 0;
+            }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    double sx = su + sc;
+    rf_wave_scan_argmax(mx, amx);
+    sx = rf_wave_scan_add(sx);
+    sp = rf_wave_scan_add(sp);
+    if (careful) {
+        su = rf_wave_scan_add(su);
+        nclip = (int)rf_wave_scan_add((unsigned)nclip);
+    } else {
+        su = sx;
+    }
+    if (lane == 63) {
+        sh.f[wave] = mx; sh.i[wave] = amx; sh.i[28 + wave] = nclip;
+        sh.d[wave * 3] = sx; sh.d[wave * 3 + 1] = sp; sh.d[wave * 3 + 2] = su;
+    }
+    __syncthreads();     // partials of scan A; the zeroed histogram
+    rf_opaque(xv);       // (keeps the compiler from carrying scan A's float64 copies of the row into scan B)
+    mx = sh.f[0]; amx = sh.i[0];
+    for (int w = 1; w < 4; ++w)
+        if (sh.f[w] > mx || (sh.f[w] == mx && sh.i[w] < amx)) { mx = sh.f[w]; amx = sh.i[w]; }
+    const double sum_x = sh.d[0] + sh.d[3] + sh.d[6] + sh.d[9];
+    const double mean = sum_x / n;
+    r.mean_p = (sh.d[1] + sh.d[4] + sh.d[7] + sh.d[10]) / n;
+    // mean ln p: ln(10^(x/10)) = x ln(10)/10 for the unclipped bins, ln(1e-15) for the clipped ones
+    r.mean_lp = ((sh.d[2] + sh.d[5] + sh.d[8] + sh.d[11]) * 0.23025850929940456840 +
+                 (double)(sh.i[28] + sh.i[29] + sh.i[30] + sh.i[31]) * -34.538776394910684) / n;
+
+    // scan B: central moments; occupied-band edges (thresholds in float32, as peak - float(drop) is) from wave
+    // ballots — bin i = 256 j + 64 wave + lane, so the first / last set bit of the first / last non-empty ballot
+    // is the wave's first / last index, kept in scalar registers; the histogram of the select
+    const float t3 = mx - 3.0f, t10 = mx - 10.0f, t20 = mx - 20.0f;
+    // histogram coordinate t(v) = 16 v - 16 (mean - 64): one fma, monotone in v; bin = floor(clamp(t, 0, 2047))
+    const float hoff = -RF_BINS_PER_DB * ((float)mean - (float)(RF_BINS / 2) / RF_BINS_PER_DB);
+    auto coord = [&](float v) { return fmaf(v, RF_BINS_PER_DB, hoff); };
+    auto bin_of = [&](float v) { return (int)fminf(fmaxf(coord(v), 0.0f), (float)(RF_BINS - 1)); };
+    double s2 = 0.0, s4 = 0.0;
+    int f3 = 0x7fffffff, l3 = -1, f10 = 0x7fffffff, l10 = -1, f20 = 0x7fffffff, l20 = -1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = tid + RF_THREADS * j;
+        const bool valid = i < n;
+        const float v = xv[j];
+        if (valid) {
+            const double dv = (double)v - mean, d2 = dv * dv;
+            s2 += d2;
+            s4 = fma(d2, d2, s4);
+            atomicAdd(&sh.bins[bin_of(v)], 1u);
+        }
+        const int i0 = RF_THREADS * j + 64 * wave;
+        const unsigned long long b20 = __ballot(valid && v >= t20);
+        if (b20) {
+            if (f20 == 0x7fffffff) f20 = i0 + __builtin_ctzll(b20);
+            l20 = i0 + 63 - __builtin_clzll(b20);
+            const unsigned long long b10 = __ballot(valid && v >= t10);
+            if (b10) {
+                if (f10 == 0x7fffffff) f10 = i0 + __builtin_ctzll(b10);
+                l10 = i0 + 63 - __builtin_clzll(b10);
+                const unsigned long long b3 = __ballot(valid && v >= t3);
+                if (b3) {
+                    if (f3 == 0x7fffffff) f3 = i0 + __builtin_ctzll(b3);
+                    l3 = i0 + 63 - __builtin_clzll(b3);
+                }
+            }
+        }
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    s2 = rf_wave_scan_add(s2);
+    s4 = rf_wave_scan_add(s4);
+    if (lane == 63) {
+        int* s = sh.i + 4 + wave * 6;
+        s[0] = f3; s[1] = l3; s[2] = f10; s[3] = l10; s[4] = f20; s[5] = l20;
+        sh.d2[wave * 2] = s2; sh.d2[wave * 2 + 1] = s4;
+    }
+    __syncthreads();     // partials of scan B; the histogram
+    rf_opaque(xv);       // (... nor scan B's bin numbers into the candidate pass)
+    for (int w = 0; w < 4; ++w) {
+        const int* s = sh.i + 4 + w * 6;
+        f3 = min(f3, s[0]); l3 = max(l3, s[1]); f10 = min(f10, s[2]); l10 = max(l10, s[3]);
+        f20 = min(f20, s[4]); l20 = max(l20, s[5]);
+    }
+    r.m2 = (sh.d2[0] + sh.d2[2] + sh.d2[4] + sh.d2[6]) / n;
+    r.m4 = (sh.d2[1] + sh.d2[3] + sh.d2[5] + sh.d2[7]) / n;
+    r.mx = mx; r.amx = amx; r.mean = mean;
+    r.f3 = f3; r.l3 = l3; r.f10 = f10; r.l10 = l10; r.f20 = f20; r.l20 = l20;
+
+    // order statistics sorted[r0], sorted[r1] (ascending) for numpy.percentile's linear interpolation
+    const unsigned r0 = (unsigned)(prm.rank < 0 ? 0 : (prm.rank > n - 1 ? n - 1 : prm.rank));
+    const unsigned r1 = r0 + 1 < (unsigned)n ? r0 + 1 : r0;
+    unsigned c[8];
+    {
+        typedef unsigned rf_v4u __attribute__((ext_vector_type(4)));
+        const rf_v4u* b4 = reinterpret_cast<const rf_v4u*>(sh.bins);
+        const rf_v4u a = b4[2 * tid], b = b4[2 * tid + 1];
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    }
+    const unsigned tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+    unsigned incl = rf_wave_scan_add(tot);
+    if (lane == 63) sh.wtot[wave] = incl;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) incl += sh.wtot[w];
+    const unsigned excl = incl - tot;
+    if (excl <= r0 && r0 < incl) {            // exactly one thread: its bins hold rank r0
+        unsigned cum = excl;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (r0 >= cum && r0 < cum + c[k]) { sh.sel[0] = 8 * tid + k; sh.sel[2] = (int)cum; }
+            cum += c[k];
+        }
+    }
+    if (excl <= r1 && r1 < incl) {
+        unsigned cum = excl;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (r1 >= cum && r1 < cum + c[k]) sh.sel[1] = 8 * tid + k;
+            cum += c[k];
+        }
     }
     __syncthreads();
-    if (!o_idx || !o_cnt) return;
+    const int b0 = __builtin_amdgcn_readfirstlane(sh.sel[0]), b1 = __builtin_amdgcn_readfirstlane(sh.sel[1]);
+    const unsigned below = (unsigned)__builtin_amdgcn_readfirstlane(sh.sel[2]);
+    // the histogram path needs finite values (NaN / inf have no bin order) and target bins inside the window
+    const double finite_probe = sum_x - sum_x;                           // 0 unless a value was NaN or +-inf
+    bool fast = __builtin_amdgcn_readfirstlane((int)(finite_probe == 0.0)) && b0 >= 1 && b1 <= RF_BINS - 2;
+    if (fast) {
+        // bins b0 .. b1 (1 <= b0 <= b1 <= 2046; the bins between them are empty: ranks r0, r1 are adjacent) hold
+        // exactly the values with b0 <= t(v) < b1 + 1
+        const float t_lo = (float)b0, t_hi = (float)(b1 + 1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = tid + RF_THREADS * j;
+            if (i < n) {
+                const float t = coord(xv[j]);
+                if (t >= t_lo && t < t_hi) {
+                    const int pos = atomicAdd(&sh.sel[3], 1);
+                    if (pos < RF_CAND) sh.cand[pos] = xv[j];
+                }
+            }
+        }
+        __syncthreads();
+        const int K = __builtin_amdgcn_readfirstlane(sh.sel[3]);
+        fast = K <= RF_CAND;
+        if (fast && wave == 0) {
+            // ascending rank inside the candidate set (ties by list position), by every lane against every candidate
+            const float mine = lane < K ? sh.cand[lane] : INFINITY;
+            unsigned rank = 0;
+            for (int j = 0; j < K; ++j) {
+                const float cj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), j));
+                rank += (cj < mine || (cj == mine && j < lane)) ? 1u : 0u;
+            }
+            const unsigned g = below + rank;
+            const unsigned long long m0 = __ballot(lane < K && g == r0), m1 = __ballot(lane < K && g == r1);
+            r.q0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), (int)__builtin_ctzll(m0 | (1ull << 63))));
+            r.q1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), (int)__builtin_ctzll(m1 | (1ull << 63))));
+        }
+    }
+    if (!fast) rf_select_pair(x, n, r0, sh, r.q0, r.q1, tid);
+    rf_finish(r, n, prm, sh, o_stats, o_thr, tid);      // (fast path: thread 0 is in wave 0, which holds q0 / q1)
+    if (o_idx && o_cnt) {
+        if (prm.min_distance >= 1 && prm.min_distance <= 16) rf_peaks_small(xv, x, n, prm, sh, o_idx, o_cnt, tid);
+        else rf_peaks(x, n, prm, sh, o_idx, o_cnt, tid);
+    }
+}
 
+// ---- greedy peak scan of a row of up to 4096 bins, min_distance <= 16 ----------------------------------------------
+// classifier.py:200-212 accepts candidates left to right when they lie >= d bins after the previously accepted one: a
+// serial recurrence, one dependent scalar chain per accepted peak (~70 clocks each; noise rows accept ~250).  Its
+// state at a word boundary is only "how many leading bins of the next 64-bin word are still suppressed" — s in
+// [0, d).  So:  (1) all four waves evaluate every word for EVERY entry state (lane = 16 word' + s, four words per
+// wave instruction) and record the exit state: a 16-nibble table per word;  (2) one wave walks the 64 tables (one
+// scalar lookup per word) and learns every word's true entry state;  (3) lane w replays word w from that state,
+// which yields its accepted bins, and the indices leave in order by a prefix sum of the counts.  Exact by
+// construction (the same recurrence, evaluated speculatively); ~4x less time on the critical wave.
+__device__ __forceinline__ void rf_accept_word(unsigned long long m, unsigned long long dspan, unsigned long long& acc) {
+    acc = 0;
+    while (__any(m != 0)) {          // wave-uniform trip count: the lane with the most accepted peaks in its word
+        if (m != 0) {
+            const int bit = __builtin_ctzll(m);
+            acc |= 1ull << bit;
+            m &= ~(dspan << bit);
+        }
+    }
+}
+
+template <class RowPtr>
+__device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, int n, const RowFeatParams& prm,
+                                               RowFeatShared& sh, int* __restrict__ o_idx, int* __restrict__ o_cnt, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double thr = sh.thr;
+    const int d = prm.min_distance;
+    const unsigned long long dspan = (1ull << d) - 1ull;
+    // candidates: strict local maxima above the threshold; word 4 j + wave holds bins 256 j + 64 wave + lane
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = tid + RF_THREADS * j;
+        bool cand = false;
+        if (i >= 1 && i < n - 1) {
+            const float v = xv[j];
+            cand = (double)v > thr && v > x[i - 1] && v > x[i + 1];
+        }
+        const unsigned long long b = __ballot(cand);
+        if (lane == 0) sh.flags[4 * j + wave] = b;
+    }
+    __syncthreads();
+    // (1) exit-state tables: wave k owns words 16 k .. 16 k + 15
+    const int st = lane & 15, grp = lane >> 4;
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+        const int w = 16 * wave + 4 * round + grp;
+        unsigned long long m = sh.flags[w] & (~0ull << st);
+        unsigned long long acc;
+        rf_accept_word(m, dspan, acc);
+        // exit state: bins of the next word still inside the last accepted peak's span
+        int ex = acc ? 63 - __builtin_clzll(acc) + d - 64 : 0;
+        ex = ex < 0 ? 0 : ex;
+        unsigned lo = st < 8 ? (unsigned)ex << (4 * st) : 0u, hi = st >= 8 ? (unsigned)ex << (4 * (st - 8)) : 0u;
+        // OR over the 16 entry states of the word (one DPP row): lane 15 of the row ends up with the table
+#define RF_STEP(CTRL)                                                                      \
+        lo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, false);    \
+        hi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, false);
+        RF_STEP(0x111) RF_STEP(0x112) RF_STEP(0x114) RF_STEP(0x118)
+#undef RF_STEP
+        if (st == 15) sh.tbl[w] = ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // (2) the walk: entry state of every word
+        const unsigned long long mine = sh.tbl[lane];
+        const int t_lo = (int)(unsigned)mine, t_hi = (int)(unsigned)(mine >> 32);
+        int entry = 0;
+        unsigned s = 0;                                    // nothing accepted before bin 0 (pk[0] = -d)
+#pragma unroll 8
+        for (int w = 0; w < 64; ++w) {
+            entry = lane == w ? (int)s : entry;
+            const unsigned long long T = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(t_hi, w) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane(t_lo, w);
+            s = (unsigned)(T >> (4 * s)) & 15u;
+        }
+        // (3) replay word `lane` from its entry state; indices out in order
+        unsigned long long acc;
+        rf_accept_word(sh.flags[lane] & (~0ull << entry), dspan, acc);
+        const unsigned pc = (unsigned)__popcll(acc);
+        const unsigned incl = rf_wave_scan_add(pc);
+        unsigned pos = incl - pc;
+        while (__any(acc != 0)) {
+            if (acc != 0) {
+                const int bit = __builtin_ctzll(acc);
+                acc &= acc - 1;
+                if ((int)pos < prm.max_peaks) o_idx[pos] = 64 * lane + bit;
+                ++pos;
+            }
+        }
+        if (lane == 63) *o_cnt = (int)incl;
+    }
+}
+
+// The whole measurement of one row by one 256-thread workgroup.  `x` points at n float32 values (LDS or global).
+// o_stats: 16 doubles; o_thr: 1 double; o_idx: max_peaks ints; o_cnt: 1 int (total peaks found, may exceed max_peaks).
+// o_idx / o_cnt / o_thr may be null (stats only).
+template <class RowPtr>
+__device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatParams& prm, RowFeatShared& sh,
+                                                double* __restrict__ o_stats, double* __restrict__ o_thr,
+                                                int* __restrict__ o_idx, int* __restrict__ o_cnt) {
+    // the thread number is re-read "opaquely" per row: inside a persistent row loop the compiler would otherwise
+    // hoist every address and lane mask derived from it out of the loop and hold ~100 registers for them
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    __builtin_assume(tid >= 0 && tid < RF_THREADS);   // (the range survives the opaque copy: bounds checks against a constant n fold)
+    if (n <= 16 * RF_THREADS) rf_small(x, n, prm, sh, o_stats, o_thr, o_idx, o_cnt, tid);
+    else rf_large(x, n, prm, sh, o_stats, o_thr, o_idx, o_cnt, tid);
+}
+
+template <class RowPtr>
+__device__ __forceinline__ void rf_peaks(RowPtr x, int n, const RowFeatParams& prm, RowFeatShared& sh,
+                                         int* __restrict__ o_idx, int* __restrict__ o_cnt, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     // greedy peak scan.  All four waves mark the candidates of a 4096-bin stretch (64 ballot words in LDS), then wave 0
     // applies the spacing rule in index order: two barriers per stretch instead of two per 256 bins.
     const double thr = sh.thr;

@@ -104,6 +104,10 @@ struct sdrk_plan {
     size_t feat_cap = 0;
     float2* d_tw_2p = nullptr;       // two-pass tiled plans (fft_tiled2.hip)
     bool tiled2 = false;
+    // overlapped form of the two-pass plans: row pass of chunk i on stream2 beside the col pass of chunk i + 1
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_col[2] = {nullptr, nullptr}, ev_row[2] = {nullptr, nullptr}, ev_fork = nullptr;
+    int col_cus = 0, row_cus = 0;    // 0: serial form
     // sdrk_exec_host pipeline: HOST_SLOTS chunks in flight, each with pinned host and device staging
     HostSlot slot[HOST_SLOTS];
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
@@ -166,6 +170,13 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
     a.d_scratch = p->d_scratch;
     a.scratch_frames = p->scratch_frames;
     a.d_twiddle_2p = p->d_tw_2p;
+    if (p->col_cus > 0 && p->stream2) {
+        a.stream2 = p->stream2;
+        a.ev_fork = p->ev_fork;
+        for (int h = 0; h < 2; ++h) { a.ev_col[h] = p->ev_col[h]; a.ev_row[h] = p->ev_row[h]; }
+        a.col_cus = p->col_cus;
+        a.row_cus = p->row_cus;
+    }
     hipError_t e = hipSuccess;
     if (p->blu_inner) {
         const int N = p->nfft, M = p->blu_m;
@@ -797,6 +808,20 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
         PLAN_TRY(hipMalloc((void**)&p->d_tw_2p, sizeof(float2) * t.size()));
         PLAN_TRY(hipMemcpy(p->d_tw_2p, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
         p->tiled2 = true;
+        // EXPERIMENT knobs (developer use): SDRK_OVERLAP=1 with SDRK_OVL_COL_CUS / SDRK_OVL_ROW_CUS
+        if (const char* env = getenv("SDRK_OVERLAP")) {
+            if (atoi(env) > 0) {
+                PLAN_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+                PLAN_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+                for (int h = 0; h < 2; ++h) {
+                    PLAN_TRY(hipEventCreateWithFlags(&p->ev_col[h], hipEventDisableTiming));
+                    PLAN_TRY(hipEventCreateWithFlags(&p->ev_row[h], hipEventDisableTiming));
+                }
+                p->col_cus = p->row_cus = p->num_cus / 2;
+                if (const char* c = getenv("SDRK_OVL_COL_CUS")) { long v = atol(c); if (v >= 1 && v <= 4096) p->col_cus = (int)v; }
+                if (const char* c = getenv("SDRK_OVL_ROW_CUS")) { long v = atol(c); if (v >= 1 && v <= 4096) p->row_cus = (int)v; }
+            }
+        }
     }
     if (flags & SDRK_PLAN_FUSED64K) {
         // Single-launch, XCD-resident form of N = 65536 (fft_fused64k.hip); shares the tables of the tiled path.
@@ -815,6 +840,12 @@ int sdrk_plan_destroy(sdrk_plan* p) {
     if (!p) return SDRK_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    for (int h = 0; h < 2; ++h) {
+        if (p->ev_col[h]) (void)hipEventDestroy(p->ev_col[h]);
+        if (p->ev_row[h]) (void)hipEventDestroy(p->ev_row[h]);
+    }
     if (p->d_window) (void)hipFree(p->d_window);
     if (p->d_twiddle) (void)hipFree(p->d_twiddle);
     if (p->d_tw_2p) (void)hipFree(p->d_tw_2p);

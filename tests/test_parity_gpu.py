@@ -620,11 +620,17 @@ def test_streamer_shim_on_gpu(pkg):
     assert len(wf) == min(n, 100) and wf.as_array().shape == (len(wf), 4096)
 
 
+# spectral flatness = exp(mean ln p) / mean p with p = 10^(x/10): the device forms p per bin with the float32
+# v_exp_f32 on an exactly reduced argument (~1e-7 relative per term) and accumulates in float64; BASELINE.json's bar
+# is 1e-5, the measured differences are < 1e-7.  Everything else of the reductions is exact or float64 (1e-9).
+FLATNESS_TOL = 1e-6
+
+
 def _check_features(got, g, k, freqs):
     s = g[f"{k}/scalars"]
     assert got["noise_floor_db"] == s[0] and got["snr_db"] == s[1], k            # exact: order statistics
     assert (got["bandwidth_hz_3db"], got["bandwidth_hz_10db"], got["bandwidth_hz_20db"]) == (s[2], s[3], s[4]), k
-    assert abs(got["spectral_flatness"] - s[5]) <= 1e-9 * max(1.0, abs(s[5])), k  # float64 sums, other order
+    assert abs(got["spectral_flatness"] - s[5]) <= FLATNESS_TOL * max(1.0, abs(s[5])), k
     assert abs(got["spectral_kurtosis"] - s[6]) <= 1e-9 * max(1.0, abs(s[6])), k
     assert got["adaptive_threshold_db"] == s[7], k
     assert np.array_equal(got["peak_idx"], g[f"{k}/peak_idx"]) and got["peak_count"] == len(g[f"{k}/peak_idx"]), k
@@ -660,7 +666,7 @@ def test_row_features_other_sizes_vs_oracle(pkg):
                     "adaptive_threshold_db", "peak_spacing_std_hz"):
             assert got[key] == ref[key], (n, key)
         assert np.array_equal(got["peak_idx"], ref["peak_idx"])
-        assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= 1e-9
+        assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= FLATNESS_TOL
         assert abs(got["spectral_kurtosis"] - ref["spectral_kurtosis"]) <= 1e-9 * ref["spectral_kurtosis"]
 
 
@@ -694,7 +700,7 @@ def test_frame_features_rows_stay_on_device(pkg, n, window):
                     "adaptive_threshold_db", "peak_spacing_std_hz"):
             assert got[r][key] == ref[key], (n, r, key)
         assert np.array_equal(got[r]["peak_idx"], ref["peak_idx"]) and got[r]["argmax"] == n // 2 + int(0.17 * n)
-        assert abs(got[r]["spectral_flatness"] - ref["spectral_flatness"]) <= 1e-9
+        assert abs(got[r]["spectral_flatness"] - ref["spectral_flatness"]) <= FLATNESS_TOL
         assert abs(got[r]["spectral_kurtosis"] - ref["spectral_kurtosis"]) <= 1e-9 * ref["spectral_kurtosis"]
         # the threshold the device formed equals the host restatement of classifier.py:46,55 to the bit
         assert got[r]["adaptive_threshold_db"] == features.adaptive_threshold(np.float32(got[r]["max_db"]),
@@ -712,12 +718,12 @@ def test_row_features_special_rows(pkg):
     got = features.row_features(flat, freqs)
     ref = cpu_ref.row_features(freqs, flat)
     assert got["peak_count"] == 0 and got["spectral_kurtosis"] == 0.0 and got["noise_floor_db"] == ref["noise_floor_db"]
-    assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= 1e-9 and got["bandwidth_hz_3db"] == ref["bandwidth_hz_3db"]
+    assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= FLATNESS_TOL and got["bandwidth_hz_3db"] == ref["bandwidth_hz_3db"]
     holes = np.linspace(-50, 10, 4096).astype(np.float32)
     holes[::7] = -np.inf
     got, ref = features.row_features(holes, freqs), cpu_ref.row_features(freqs, holes)
     assert got["noise_floor_db"] == ref["noise_floor_db"] and got["bandwidth_hz_20db"] == ref["bandwidth_hz_20db"]
-    assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= 1e-9
+    assert abs(got["spectral_flatness"] - ref["spectral_flatness"]) <= FLATNESS_TOL
     nan_row = np.full(64, np.nan, dtype=np.float32)
     got = features.row_features(nan_row, cpu_ref.freq_axis(64, 1e6, 0.0))
     assert got["bandwidth_hz_3db"] == 0.0 and got["peak_count"] == 0

@@ -23,6 +23,14 @@ with SpectrumPlan(n, window="hann") as plan:
         print(f"fused peaks={peaks}: {dt*1e3:.3f} ms, {dt/nf*1e9:.1f} ns/row", flush=True)
     plan.exec_device(b["iq"].value, nf, b["rows"].value); plan.sync()
     t0 = time.perf_counter(); plan.exec_device(b["iq"].value, nf, b["rows"].value); plan.sync(); print(f"transform only: {(time.perf_counter()-t0)*1e3:.3f} ms")
+    # the stand-alone single-read reduction kernel over rows already in HBM (results to the host, as sdrk_row_features does)
+    host = {"stats": np.empty((nf, 16)), "thr": np.empty(nf), "idx": np.empty((nf, mp), dtype=np.int32), "cnt": np.empty(nf, dtype=np.int32)}
+    hp = {k: v.ctypes.data_as(ctypes.c_void_p) for k, v in host.items()}
+    def alone():
+        _ffi.check(lib.sdrk_row_features(0, b["rows"], 1, nf, n, rank, ctypes.c_float(gamma), 13, mp, hp["stats"], hp["thr"], hp["idx"], hp["cnt"]))
+    alone()
+    t0 = time.perf_counter(); alone(); dt = time.perf_counter() - t0
+    print(f"stand-alone kernel + D2H of results: {dt*1e3:.3f} ms, {dt/nf*1e9:.1f} ns/row", flush=True)
 cnt = np.empty(nf, dtype=np.int32)
 _ffi.check(lib.sdrk_memcpy_d2h(0, cnt.ctypes.data_as(ctypes.c_void_p), b["cnt"], cnt.nbytes))
 print("peaks per row: mean", cnt.mean(), "max", cnt.max())
