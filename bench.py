@@ -355,7 +355,31 @@ def numpy_boundary(lib, _ffi, pkg, synth, dev):
             rec["reused_out_ms_per_call"] = round(_median(ts) * 1e3, 4)
             rec["reused_out_input_GBps"] = round(bsz * NFFT * 8 / _median(ts) / 1e9, 2)
             rec["reused_out_frac_of_duplex_link"] = round(bsz * NFFT * 8 / _median(ts) / 1e9 / c.value, 3)
+        if bsz >= 4096:                                         # input and result in pinned arrays: no staging copies
+            xp, rp = pkg.pinned_empty(x.shape, np.complex64), pkg.pinned_empty(x.shape, np.float32)
+            xp[...] = x
+            pkg.spectrum_db(xp, device=dev, out=rp)
+            ts, cpu = [], []
+            for _ in range(reps):
+                c0, t0 = time.process_time(), time.perf_counter()
+                pkg.spectrum_db(xp, device=dev, out=rp)
+                ts.append(time.perf_counter() - t0)
+                cpu.append(time.process_time() - c0)
+            gib = bsz * NFFT * 8 / 2 ** 30
+            rec["pinned_ms_per_call"] = round(_median(ts) * 1e3, 4)
+            rec["pinned_input_GBps"] = round(bsz * NFFT * 8 / _median(ts) / 1e9, 2)
+            rec["pinned_frac_of_duplex_link"] = round(bsz * NFFT * 8 / _median(ts) / 1e9 / c.value, 3)
+            rec["pinned_host_cpu_ms_per_GiB"] = round(_median(cpu) * 1e3 / gib, 2)
+            cpu = []
+            for _ in range(reps):                               # the same for the staged pageable path (result reused)
+                c0 = time.process_time()
+                pkg.spectrum_db(x, device=dev, out=res)
+                cpu.append(time.process_time() - c0)
+            rec["pageable_host_cpu_ms_per_GiB"] = round(_median(cpu) * 1e3 / gib, 2)
+            del xp, rp
         out["by_batch"][f"B{bsz}"] = rec
+    out["pinned_what"] = ("input and result in pkg.pinned_empty arrays (sdrk_host_alloc): chunks are DMA'd straight from / to the "
+                          "caller's memory; host_cpu = process CPU time (all threads) per GiB of input")
     return out
 
 

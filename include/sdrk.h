@@ -92,6 +92,22 @@ int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, in
 int sdrk_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes);
 int sdrk_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes);
 
+/* ---- pinned host memory for the numpy boundary ---------------------------------
+ * sdrk_exec_host / sdrk_exec_fft_host stage pageable caller arrays through pinned slots with a pool of copy
+ * threads (host_pool.h) — about 100 GB/s per process however many GPUs it drives.  Arrays that live in PINNED
+ * host memory skip that: their chunks are DMA'd straight from / to the caller's memory, no host copy and no
+ * host thread involved, so the boundary scales with the number of GPUs ("host gather via per-GPU
+ * D2H into slices of one pinned array").  Either let the library allocate (sdrk_host_alloc: page-locked, visible
+ * to every device) or register memory of your own (sdrk_host_register: the range must stay mapped until
+ * sdrk_host_unregister — a numpy array must outlive its registration).  exec_host recognises any range that lies
+ * inside such an allocation; input and output are decided independently. */
+int sdrk_host_alloc(size_t bytes, void** h_ptr);
+int sdrk_host_free(void* h_ptr);
+int sdrk_host_register(void* h_ptr, size_t bytes);
+int sdrk_host_unregister(void* h_ptr);
+/* 1 if [h_ptr, h_ptr + bytes) lies inside memory made known by the calls above, else 0. */
+int sdrk_host_is_pinned(const void* h_ptr, size_t bytes);
+
 /* ---- spectrum plan -------------------------------------------------------
  * Replaces streamer.py:119,121 for frames of nfft complex64 samples:
  *     out_db[k] = 20*log10( | fftshift( fft( w * x ) ) |[k] + eps )     (float32)
@@ -111,6 +127,11 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind,
  * launch whose per-frame intermediate stays in each XCD's L2 (fft_fused64k.hip) instead of the two
  * tiled launches — an experiment kept for A/B work (less HBM traffic, but slower: DESIGN.md §4.4). */
 #define SDRK_PLAN_FUSED64K 0x1u
+/* SDRK_PLAN_OVERLAP_PASSES (power-of-two nfft >= 2^15): run the row pass of chunk i on a second stream beside the
+ * col pass of chunk i + 1, each on its own half of the scratch and on its own share of the CUs.  Bit-identical
+ * rows; kept for A/B work like the flag above — measured 20-35 % SLOWER than the serial two-launch form on
+ * BASELINE configs 3 and 5 (profiles/r03/overlap_probe.log). */
+#define SDRK_PLAN_OVERLAP_PASSES 0x2u
 int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
                         const float* window, float eps, int shift, unsigned flags, sdrk_plan** out);
 /* Large-frame plans (nfft >= 2^15) keep their two-pass intermediate in a scratch buffer, and — like the resident

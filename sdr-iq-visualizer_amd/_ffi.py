@@ -31,6 +31,7 @@ WINDOW_CUSTOM = 2
 
 MAX_LOG2_NFFT = 22
 PLAN_FUSED64K = 0x1
+PLAN_OVERLAP_PASSES = 0x2
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # SDRK_LIB: developer override (A/B builds made by tools/variant.sh); the product loads lib/libsdrk.so
@@ -78,6 +79,11 @@ SYMBOLS = [
     ("sdrk_exec_device_timed_each", c_int,
      [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float)]),
     ("sdrk_stream_ceiling_probe", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_float)]),
+    ("sdrk_host_alloc", c_int, [c_size_t, POINTER(c_void_p)]),
+    ("sdrk_host_free", c_int, [c_void_p]),
+    ("sdrk_host_register", c_int, [c_void_p, c_size_t]),
+    ("sdrk_host_unregister", c_int, [c_void_p]),
+    ("sdrk_host_is_pinned", c_int, [c_void_p, c_size_t]),
     ("sdrk_copy_probe", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_float)]),
     ("sdrk_host_link_probe", c_int, [c_int, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     ("sdrk_host_threads", c_int, []),

@@ -33,14 +33,22 @@ __global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kern
     float* __restrict__ row = reinterpret_cast<float*>(lds);                                  // 4096 float32
     RowFeatShared& sh = *reinterpret_cast<RowFeatShared*>(reinterpret_cast<char*>(lds) + F4K_N * sizeof(float));
 
-    const int tid = threadIdx.x;
-    F4kAddr A = f4k_addr(tid);
-    f4k_init_tables(tw256, tw4k, tw4096, tid, A);
+    {
+        const int tid = threadIdx.x;
+        F4kAddr A = f4k_addr(tid);
+        f4k_init_tables(tw256, tw4k, tw4096, tid, A);
+    }
     __syncthreads();
 
     const int xor_k2 = shift ? 8 : 0;
     const __amdgpu_buffer_rsrc_t rwin = frame_rsrc(window, HAS_WINDOW ? F4K_N * 4 : 0);
     for (size_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        // the thread's LDS / buffer offsets are re-derived per frame from an opaque copy of its number (a dozen
+        // integer operations): hoisted out of this persistent loop they would be live across the reductions too
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < F4K_THREADS);
+        const F4kAddr A = f4k_addr(tid);
         cf v[16];
         {
             const __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + f * frame_stride, F4K_N * 8);

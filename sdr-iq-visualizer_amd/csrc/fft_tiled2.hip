@@ -399,11 +399,8 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
     constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, WGT = T * 8;
     static_assert((size_t)M * 17 * sizeof(float) <= (size_t)8 * C::SLOT * sizeof(float2), "transpose tile must fit the exchange area");
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];   // 8 x SLOT; complex epilogue: at least [M][9] float2
-    const int tid = threadIdx.x;
-    const int fr = tid / T, rt = tid - fr * T;
-    float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
     LdsTw<LOG2M> tw;
-    lds_tw_init<LOG2M>(tw, twM, rt);
+    lds_tw_init<LOG2M>(tw, twM, (int)threadIdx.x % T);
     const size_t nfft = (size_t)A * M;
     const int bands = A / 16;
     const size_t items = n_frames * (size_t)bands;
@@ -412,6 +409,14 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
         const size_t f = g / bands;
         const int k3_0 = (int)(g - f * bands) * 16;
         const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)k3_0 * M, (unsigned)(16 * M * 8));
+        // the thread's coordinates are re-derived per band from an opaque copy of its number: hoisted out of this
+        // persistent loop, the dozen LDS / buffer offsets derived from them cost the registers that the first
+        // half's 16 parked dB values then lack (128-VGPR cap at four waves per SIMD: 12 / 24 bytes of scratch)
+        int tid_o = threadIdx.x;
+        asm volatile("" : "+v"(tid_o));
+        __builtin_assume(tid_o >= 0 && tid_o < WGT);
+        const int fr = tid_o / T, rt = tid_o - fr * T, tid = tid_o;
+        float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
         float val[2][16];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -61,6 +62,25 @@ int check_device(int device) {
 
 bool is_pow2(long long v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Pinned host ranges the library knows about (sdrk_host_alloc / sdrk_host_register): start -> (bytes, owned)
+struct PinnedRanges {
+    std::mutex m;
+    std::map<uintptr_t, std::pair<size_t, bool>> r;
+    bool covers(const void* p, size_t bytes) {
+        if (!p || bytes == 0) return false;
+        std::lock_guard<std::mutex> g(m);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        auto it = r.upper_bound(a);
+        if (it == r.begin()) return false;
+        --it;
+        return a >= it->first && a + bytes <= it->first + it->second.first;
+    }
+};
+PinnedRanges& pinned_ranges() {
+    static PinnedRanges pr;
+    return pr;
+}
+
 // exp(-2 pi i m / n) in double, rounded once to float32.
 float2 twiddle(double m, double n) {
     const double a = -2.0 * M_PI * m / n;
@@ -77,6 +97,7 @@ struct HostSlot {
     size_t in_cap = 0, out_cap = 0;
     hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_done = nullptr;
     // the chunk in flight in this slot (busy == true): where its rows go once ev_done has fired
+    // (user_out == nullptr: the rows were DMA'd straight into the caller's pinned array)
     bool busy = false;
     void* user_out = nullptr;
     size_t out_bytes = 0;
@@ -314,7 +335,7 @@ int slot_retire(HostSlot& s, HostTrace& tr) {
     const double t0 = tr.on ? HostTrace::now() : 0;
     HIP_TRY(hipEventSynchronize(s.ev_done));
     const double t1 = tr.on ? HostTrace::now() : 0;
-    sdrk::CopyPool::get().copy(s.user_out, s.h_out, s.out_bytes);
+    if (s.user_out) sdrk::CopyPool::get().copy(s.user_out, s.h_out, s.out_bytes);
     if (tr.on) { tr.t_wait += t1 - t0; tr.t_out += HostTrace::now() - t1; }
     return SDRK_OK;
 }
@@ -411,7 +432,11 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
     // 0.44 ms against the DMA form; equal at 32 MiB).  Large calls, overlapped frames (the halo would cross PCIe
     // twice) and the two-pass kernels (their 128-byte column segments read host memory at half the DMA rate:
     // 26 vs 48 GB/s at N = 65536) use the copy engines.
-    const bool zero_copy = p->nfft <= 16384 && !p->blu_inner && frame_stride >= nfft && in_bytes <= ZERO_COPY_MAX_BYTES;
+    // Caller arrays in pinned memory (sdrk_host_alloc / sdrk_host_register) are not staged: the copy engines read
+    // and write them directly.  Decided per side.
+    const bool in_pinned = pinned_ranges().covers(iq, in_bytes), out_pinned = pinned_ranges().covers(out, out_bytes);
+    const bool zero_copy = p->nfft <= 16384 && !p->blu_inner && frame_stride >= nfft && in_bytes <= ZERO_COPY_MAX_BYTES &&
+                           !in_pinned && !out_pinned;
     const double t_call = tr.on ? HostTrace::now() : 0;
     size_t c = 0;
     for (size_t f0 = 0; f0 < n_frames; f0 += per, ++c) {
@@ -423,7 +448,12 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
         if (st == SDRK_OK) st = slot_reserve(p, s, chunk_in, chunk_out);
         if (st != SDRK_OK) { slots_abandon(p); return st; }
         const double t0 = tr.on ? HostTrace::now() : 0;
-        pool.copy(s.h_in, static_cast<const float2*>(iq) + f0 * frame_stride, cin);
+        const void* src = static_cast<const float2*>(iq) + f0 * frame_stride;
+        if (!in_pinned) {
+            pool.copy(s.h_in, src, cin);
+            src = s.h_in;
+        }
+        void* user_rows = static_cast<char*>(out) + f0 * nfft * out_elem;
         if (tr.on) tr.t_in += HostTrace::now() - t0;
         hipError_t e = hipSuccess;
         if (zero_copy) {
@@ -433,7 +463,7 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
             if (st != SDRK_OK) { slots_abandon(p); return st; }
             e = hipEventRecord(s.ev_done, p->stream);
         } else {
-            e = hipMemcpyAsync(s.d_in, s.h_in, cin, hipMemcpyHostToDevice, p->s_h2d);
+            e = hipMemcpyAsync(s.d_in, src, cin, hipMemcpyHostToDevice, p->s_h2d);
             if (e == hipSuccess) e = hipEventRecord(s.ev_in, p->s_h2d);
             if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, s.ev_in, 0);
             if (e == hipSuccess) {
@@ -442,7 +472,7 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
                 e = hipEventRecord(s.ev_k, p->stream);
             }
             if (e == hipSuccess) e = hipStreamWaitEvent(p->s_d2h, s.ev_k, 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(s.h_out, s.d_out, cout, hipMemcpyDeviceToHost, p->s_d2h);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_pinned ? user_rows : s.h_out, s.d_out, cout, hipMemcpyDeviceToHost, p->s_d2h);
             if (e == hipSuccess) e = hipEventRecord(s.ev_done, p->s_d2h);
         }
         if (e != hipSuccess) {
@@ -450,7 +480,7 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
             return fail(SDRK_ERR_HIP, "host pipeline failed: %s", hipGetErrorString(e));
         }
         s.busy = true;
-        s.user_out = static_cast<char*>(out) + f0 * nfft * out_elem;
+        s.user_out = (out_pinned && !zero_copy) ? nullptr : user_rows;
         s.out_bytes = cout;
     }
     for (size_t i = 0; i < HOST_SLOTS; ++i) {                  // drain in submission order
@@ -666,6 +696,61 @@ int sdrk_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes) {
     return SDRK_OK;
 }
 
+int sdrk_host_alloc(size_t bytes, void** h_ptr) {
+    if (!h_ptr) return fail(SDRK_ERR_INVALID, "h_ptr is NULL");
+    *h_ptr = nullptr;
+    if (bytes == 0) return fail(SDRK_ERR_INVALID, "bytes must be >= 1");
+    int st = check_device(0);
+    if (st != SDRK_OK) return st;
+    HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocPortable));
+    std::lock_guard<std::mutex> g(pinned_ranges().m);
+    pinned_ranges().r[reinterpret_cast<uintptr_t>(*h_ptr)] = {bytes, true};
+    return SDRK_OK;
+}
+
+int sdrk_host_free(void* h_ptr) {
+    if (!h_ptr) return SDRK_OK;
+    {
+        std::lock_guard<std::mutex> g(pinned_ranges().m);
+        auto it = pinned_ranges().r.find(reinterpret_cast<uintptr_t>(h_ptr));
+        if (it == pinned_ranges().r.end() || !it->second.second)
+            return fail(SDRK_ERR_INVALID, "pointer was not returned by sdrk_host_alloc");
+        pinned_ranges().r.erase(it);
+    }
+    HIP_TRY(hipHostFree(h_ptr));
+    return SDRK_OK;
+}
+
+int sdrk_host_register(void* h_ptr, size_t bytes) {
+    if (!h_ptr || bytes == 0) return fail(SDRK_ERR_INVALID, "NULL pointer or zero bytes");
+    int st = check_device(0);
+    if (st != SDRK_OK) return st;
+    {
+        std::lock_guard<std::mutex> g(pinned_ranges().m);
+        if (pinned_ranges().r.count(reinterpret_cast<uintptr_t>(h_ptr)))
+            return fail(SDRK_ERR_INVALID, "range is already registered");
+    }
+    HIP_TRY(hipHostRegister(h_ptr, bytes, hipHostRegisterPortable));
+    std::lock_guard<std::mutex> g(pinned_ranges().m);
+    pinned_ranges().r[reinterpret_cast<uintptr_t>(h_ptr)] = {bytes, false};
+    return SDRK_OK;
+}
+
+int sdrk_host_unregister(void* h_ptr) {
+    if (!h_ptr) return SDRK_OK;
+    {
+        std::lock_guard<std::mutex> g(pinned_ranges().m);
+        auto it = pinned_ranges().r.find(reinterpret_cast<uintptr_t>(h_ptr));
+        if (it == pinned_ranges().r.end() || it->second.second)
+            return fail(SDRK_ERR_INVALID, "pointer was not registered with sdrk_host_register");
+        pinned_ranges().r.erase(it);
+    }
+    HIP_TRY(hipHostUnregister(h_ptr));
+    return SDRK_OK;
+}
+
+int sdrk_host_is_pinned(const void* h_ptr, size_t bytes) { return pinned_ranges().covers(h_ptr, bytes) ? 1 : 0; }
+
 int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind, const float* window,
                      float eps, int shift, sdrk_plan** out) {
     return sdrk_plan_create_ex(device, nfft, max_batch, window_kind, window, eps, shift, 0u, out);
@@ -675,7 +760,12 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
                         float eps, int shift, unsigned flags, sdrk_plan** out) {
     if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (flags & ~(unsigned)SDRK_PLAN_FUSED64K) return fail(SDRK_ERR_INVALID, "unknown plan flags 0x%x", flags);
+    if (flags & ~(unsigned)(SDRK_PLAN_FUSED64K | SDRK_PLAN_OVERLAP_PASSES))
+        return fail(SDRK_ERR_INVALID, "unknown plan flags 0x%x", flags);
+    if ((flags & SDRK_PLAN_OVERLAP_PASSES) && (!is_pow2(nfft) || nfft < (1 << 15)))
+        return fail(SDRK_ERR_INVALID, "SDRK_PLAN_OVERLAP_PASSES applies to power-of-two nfft >= 32768 (got %d)", nfft);
+    if ((flags & SDRK_PLAN_OVERLAP_PASSES) && (flags & SDRK_PLAN_FUSED64K))
+        return fail(SDRK_ERR_INVALID, "SDRK_PLAN_OVERLAP_PASSES and SDRK_PLAN_FUSED64K exclude each other");
     if ((flags & SDRK_PLAN_FUSED64K) && nfft != 65536)
         return fail(SDRK_ERR_INVALID, "SDRK_PLAN_FUSED64K applies to nfft = 65536 only (got %d)", nfft);
     if (nfft < 2 || nfft > (1 << SDRK_MAX_LOG2_NFFT) || (!is_pow2(nfft) && nfft > (1 << (SDRK_MAX_LOG2_NFFT - 1))))
@@ -808,19 +898,20 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
         PLAN_TRY(hipMalloc((void**)&p->d_tw_2p, sizeof(float2) * t.size()));
         PLAN_TRY(hipMemcpy(p->d_tw_2p, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
         p->tiled2 = true;
-        // EXPERIMENT knobs (developer use): SDRK_OVERLAP=1 with SDRK_OVL_COL_CUS / SDRK_OVL_ROW_CUS
-        if (const char* env = getenv("SDRK_OVERLAP")) {
-            if (atoi(env) > 0) {
-                PLAN_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
-                PLAN_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-                for (int h = 0; h < 2; ++h) {
-                    PLAN_TRY(hipEventCreateWithFlags(&p->ev_col[h], hipEventDisableTiming));
-                    PLAN_TRY(hipEventCreateWithFlags(&p->ev_row[h], hipEventDisableTiming));
-                }
-                p->col_cus = p->row_cus = p->num_cus / 2;
-                if (const char* c = getenv("SDRK_OVL_COL_CUS")) { long v = atol(c); if (v >= 1 && v <= 4096) p->col_cus = (int)v; }
-                if (const char* c = getenv("SDRK_OVL_ROW_CUS")) { long v = atol(c); if (v >= 1 && v <= 4096) p->row_cus = (int)v; }
+        if (flags & SDRK_PLAN_OVERLAP_PASSES) {
+            // second stream, the events that chain the two, and the split of the CUs between the roles: 3/4 of
+            // the device's CUs worth of col workgroups, 1/2 worth of row workgroups (the least slow of the splits
+            // tried; SDRK_OVL_COL_CUS / SDRK_OVL_ROW_CUS override it for the sweep in tools/overlap_probe.py)
+            PLAN_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+            PLAN_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            for (int h = 0; h < 2; ++h) {
+                PLAN_TRY(hipEventCreateWithFlags(&p->ev_col[h], hipEventDisableTiming));
+                PLAN_TRY(hipEventCreateWithFlags(&p->ev_row[h], hipEventDisableTiming));
             }
+            p->col_cus = p->num_cus * 3 / 4 > 0 ? p->num_cus * 3 / 4 : 1;
+            p->row_cus = p->num_cus / 2 > 0 ? p->num_cus / 2 : 1;
+            if (const char* c = getenv("SDRK_OVL_COL_CUS")) { long v = atol(c); if (v >= 1 && v <= 4096) p->col_cus = (int)v; }
+            if (const char* c = getenv("SDRK_OVL_ROW_CUS")) { long v = atol(c); if (v >= 1 && v <= 4096) p->row_cus = (int)v; }
         }
     }
     if (flags & SDRK_PLAN_FUSED64K) {

@@ -125,30 +125,48 @@ def _local_device(rank: int) -> int:
     return d % n if n > 0 else d
 
 
-def distributed_spectrum_db(samples, *, window=None, eps: float = 1e-12, shift: bool = True,
+def distributed_spectrum_db(samples=None, *, window=None, eps: float = 1e-12, shift: bool = True,
                             device: Optional[int] = None, dst: int = 0, group=None,
-                            compute: Optional[Callable[[np.ndarray], np.ndarray]] = None):
-    """One-process-per-GPU form.  Every rank passes the same ``(B, N)`` batch (or a
-    lazily-indexable view of it); rank r transforms frames ``rank_range(B, r, W)``
-    on its own GPU and rank ``dst`` returns the gathered ``(B, N)`` float32 array
-    (other ranks return ``None``).  The rank's GPU is ``device``, else ``LOCAL_RANK``.  The gather moves host
-    arrays and therefore runs over a CPU (gloo) group, also when the job's backend is nccl.  ``compute`` replaces the per-rank transform —
-    the CPU test-suite injects the oracle there to exercise the sharding and the
-    gather under gloo without a GPU; the product default is the HIP path."""
+                            compute: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+                            local_frames=None, n_frames_total: Optional[int] = None):
+    """One-process-per-GPU form.  Rank r transforms frames ``rank_range(B, r, W)`` on its own GPU and rank ``dst``
+    returns the gathered ``(B, N)`` float32 array (other ranks return ``None``).  Two ways to hand the frames over:
+
+    * ``samples``: every rank passes the same ``(B, N)`` batch (or a lazily-indexable view of it) and takes its
+      range from it — convenient for tests and small batches;
+    * ``local_frames`` + ``n_frames_total``: every rank passes ONLY its own range, ``(hi - lo, N)`` with
+      ``(lo, hi) = rank_range(n_frames_total, rank, world)`` — what a job at BASELINE config 4's size has to do
+      (256 GiB of IQ in aggregate: no rank can hold the whole batch).
+
+    The rank's GPU is ``device``, else ``LOCAL_RANK``.  The gather moves host arrays and therefore runs over a CPU
+    (gloo) group, also when the job's backend is nccl.  ``compute`` replaces the per-rank transform — the CPU
+    test-suite injects the oracle there to exercise the sharding and the gather under gloo without a GPU; the
+    product default is the HIP path."""
     import torch
     import torch.distributed as dist
 
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    n_frames, nfft = int(samples.shape[0]), int(samples.shape[1])
-    lo, hi = rank_range(n_frames, rank, world)
+    if (samples is None) == (local_frames is None):
+        raise ValueError("pass either samples (the whole batch) or local_frames + n_frames_total (this rank's range)")
+    if local_frames is not None:
+        if n_frames_total is None:
+            raise ValueError("local_frames needs n_frames_total")
+        n_frames, nfft = int(n_frames_total), int(local_frames.shape[1])
+        lo, hi = rank_range(n_frames, rank, world)
+        if int(local_frames.shape[0]) != hi - lo:
+            raise ValueError(f"rank {rank} of {world} owns frames [{lo}, {hi}) of {n_frames}: expected {hi - lo} local "
+                             f"frames, got {int(local_frames.shape[0])}")
+    else:
+        n_frames, nfft = int(samples.shape[0]), int(samples.shape[1])
+        lo, hi = rank_range(n_frames, rank, world)
     use_cuda = dist.get_backend(group) == "nccl"
     if device is None and (compute is None or use_cuda):
         device = _local_device(rank)
     if compute is None:
         compute = _default_compute(window, eps, shift, device)
-    mine = np.ascontiguousarray(samples[lo:hi])
+    mine = np.ascontiguousarray(local_frames if local_frames is not None else samples[lo:hi])
     rows = compute(mine) if hi > lo else np.empty((0, nfft), dtype=np.float32)
     rows = np.ascontiguousarray(rows, dtype=np.float32)
 

@@ -67,7 +67,8 @@ class SpectrumPlan:
     """
 
     def __init__(self, nfft: int, *, window: WindowArg = None, eps: float = 1e-12,
-                 shift: bool = True, device: int = 0, max_batch: int = 1 << 30, fused64k: bool = False):
+                 shift: bool = True, device: int = 0, max_batch: int = 1 << 30, fused64k: bool = False,
+                 overlap_passes: bool = False):
         nfft = int(nfft)
         pow2 = nfft >= 2 and not (nfft & (nfft - 1))
         if nfft < 2 or nfft > (1 << _ffi.MAX_LOG2_NFFT) or (not pow2 and nfft > (1 << (_ffi.MAX_LOG2_NFFT - 1))):
@@ -86,7 +87,9 @@ class SpectrumPlan:
         # fused64k: the experimental single-launch form of N = 65536; an explicit plan
         # option, so the path taken is visible in the API and in the plan cache key
         self.fused64k = bool(fused64k)
-        flags = _ffi.PLAN_FUSED64K if self.fused64k else 0
+        # overlap_passes: the two passes of a large frame on two streams (slower, kept for A/B)
+        self.overlap_passes = bool(overlap_passes)
+        flags = (_ffi.PLAN_FUSED64K if self.fused64k else 0) | (_ffi.PLAN_OVERLAP_PASSES if self.overlap_passes else 0)
         check(lib().sdrk_plan_create_ex(self.device, nfft, c_size_t(int(max_batch)), kind, wptr,
                                         c_float(self.eps), int(self.shift), flags, byref(self._handle)))
 

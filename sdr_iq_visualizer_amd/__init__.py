@@ -26,6 +26,7 @@ from .spectrum import (  # noqa: E402
     welch_psd,
 )
 from .waterfall import WaterfallBuffer  # noqa: E402
+from .hostmem import is_pinned, pinned_empty, registered  # noqa: E402
 from ._ffi import SdrkError, device_count, device_info, library_path  # noqa: E402
 
 __all__ = [
@@ -36,8 +37,11 @@ __all__ = [
     "device_info",
     "fft_c64",
     "freq_axis",
+    "is_pinned",
     "library_path",
+    "pinned_empty",
     "process_frame",
+    "registered",
     "spectrum_db",
     "stft_db",
     "welch_psd",

@@ -15,7 +15,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_frames, nfft, q):
+def _worker(rank, world, port, n_frames, nfft, q, local_only=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -31,8 +31,16 @@ def _worker(rank, world, port, n_frames, nfft, q):
             seen.append(frames.shape[0])
             return cpu_ref.spectrum_db(frames)
 
-        out = sharding.distributed_spectrum_db(x, compute=compute, dst=0)
         lo, hi = sharding.rank_range(n_frames, rank, world)
+        if local_only:
+            # the rank holds ONLY its own frames (BASELINE config 4's shape: nobody can hold the whole batch)
+            mine = synth.synth_iq(77, lo, hi - lo, nfft)
+            out = sharding.distributed_spectrum_db(local_frames=mine, n_frames_total=n_frames, compute=compute, dst=0)
+            with pytest.raises(ValueError):
+                sharding.distributed_spectrum_db(local_frames=mine[:0] if hi - lo else x[:1], n_frames_total=n_frames + 7,
+                                                 compute=compute, dst=0)
+        else:
+            out = sharding.distributed_spectrum_db(x, compute=compute, dst=0)
         assert seen == ([hi - lo] if hi > lo else [])
         if rank == 0:
             q.put(out)
@@ -43,15 +51,15 @@ def _worker(rank, world, port, n_frames, nfft, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [6, 5, 1])
-def test_two_rank_frame_range_sharding_and_gather(n_frames):
+@pytest.mark.parametrize("n_frames,local_only", [(6, False), (5, False), (1, False), (5, True), (8, True)])
+def test_two_rank_frame_range_sharding_and_gather(n_frames, local_only):
     import torch.multiprocessing as mp
     from oracle import cpu_ref
     from sdr_iq_visualizer_amd import synth
     nfft, world, port = 256, 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, nfft, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, nfft, q, local_only)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=120)

@@ -805,6 +805,88 @@ def test_fused_n65536_agrees_with_two_launch_path(pkg):
             lib.sdrk_dev_free(0, d)
 
 
+def test_overlapped_passes_agree_with_serial_form(pkg):
+    """SDRK_PLAN_OVERLAP_PASSES (row pass of chunk i on a second stream beside the col pass of chunk i + 1, two scratch
+    halves, events between the streams): the same kernels in another order, so every row must equal the serial form's
+    bit for bit — a half of the scratch handed over early or late would corrupt whole chunks.  Device-resident runs
+    long enough for hundreds of hand-overs (N = 65536, 50 % overlap) and a few (N = 2^20), then the host-array forms."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    for n, rows, stride in ((65536, 6001, 32768), (1 << 20, 80, 1 << 20)):
+        in_samples = (rows - 1) * stride + n
+        d_in, d_a, d_b = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _ffi.check(lib.sdrk_dev_alloc(0, (in_samples + 4095) // 4096 * 4096 * 8, ctypes.byref(d_in)))
+        _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_a)))
+        _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_b)))
+        try:
+            _ffi.check(lib.sdrk_synth_fill(0, 41, 0, (in_samples + 4095) // 4096, 4096, d_in, None))
+            with SpectrumPlan(n, window="hann", overlap_passes=True) as po, SpectrumPlan(n, window="hann") as ps:
+                for _ in range(2):
+                    po.exec_device(d_in.value, rows, d_a.value, frame_stride=stride)
+                po.sync()
+                ps.exec_device(d_in.value, rows, d_b.value, frame_stride=stride)
+                ps.sync()
+            a = np.empty(n, dtype=np.float32)
+            b = np.empty(n, dtype=np.float32)
+            step = max(1, rows // 97)
+            for f in list(range(0, rows, step)) + [rows - 1]:
+                _ffi.check(lib.sdrk_memcpy_d2h(0, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_a.value + f * n * 4), n * 4))
+                _ffi.check(lib.sdrk_memcpy_d2h(0, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_b.value + f * n * 4), n * 4))
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"N={n} frame {f} differs"
+        finally:
+            for d in (d_in, d_a, d_b):
+                lib.sdrk_dev_free(0, d)
+    rng = np.random.default_rng(8)
+    x = rand_c64(rng, 9, 1 << 17, scale=4.0)
+    with SpectrumPlan(1 << 17, overlap_passes=True) as po, SpectrumPlan(1 << 17) as ps:
+        assert np.array_equal(po.spectrum_db(x), ps.spectrum_db(x)) and np.array_equal(po.fft(x), ps.fft(x))
+    with pytest.raises(ValueError):
+        SpectrumPlan(4096, overlap_passes=True)                         # one-pass lengths have nothing to overlap
+
+
+def test_pinned_host_arrays_are_not_staged(pkg):
+    """Caller arrays in pinned memory (pinned_empty / registered) go through the copy engines directly: same rows, bit
+    for bit, as the staged pageable path — either side pinned, both, large and mid-size calls, overlapped frames,
+    the thread-per-device form writing slices of one pinned result."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi
+    rng = np.random.default_rng(12)
+    for n, b in ((4096, 3000), (4096, 100), (16384, 700), (65536, 40)):
+        x = rand_c64(rng, b, n, scale=20.0)
+        ref = pkg.spectrum_db(x)                                  # pageable in, pageable out
+        xp = pkg.pinned_empty((b, n), np.complex64)
+        xp[...] = x
+        rp = pkg.pinned_empty((b, n), np.float32)
+        assert pkg.is_pinned(xp) and pkg.is_pinned(rp) and pkg.is_pinned(rp[3:7]) and not pkg.is_pinned(x)
+        rp.fill(np.nan)
+        assert pkg.spectrum_db(xp, out=rp) is rp and np.array_equal(rp, ref), (n, b, "both pinned")
+        assert np.array_equal(pkg.spectrum_db(xp), ref), (n, b, "pinned in")
+        rp.fill(np.nan)
+        pkg.spectrum_db(x, out=rp)
+        assert np.array_equal(rp, ref), (n, b, "pinned out")
+        assert np.array_equal(pkg.fft_c64(xp), pkg.fft_c64(x))
+    stream = rand_c64(rng, 1, 50 * 32768 + 65536, scale=3.0)[0]
+    sp = pkg.pinned_empty(stream.shape, np.complex64)
+    sp[...] = stream
+    assert np.array_equal(pkg.stft_db(sp, 65536, 32768, "hann"), pkg.stft_db(stream, 65536, 32768, "hann"))
+    # an existing array, page-locked for the duration of a block
+    y = rand_c64(rng, 2000, 4096, scale=5.0)
+    ref = pkg.spectrum_db(y)
+    with pkg.registered(y):
+        assert pkg.is_pinned(y) and np.array_equal(pkg.spectrum_db(y), ref)
+    assert not pkg.is_pinned(y)
+    # SURVEY.md §8(e): per-GPU D2H into slices of one pinned array
+    devs = visible_devices(pkg)
+    gather = pkg.pinned_empty((2000, 4096), np.float32)
+    pkg.spectrum_db(y, devices=devs, out=gather)
+    assert np.array_equal(gather, ref)
+    with pytest.raises(ValueError):
+        _ffi.check(_ffi.lib().sdrk_host_free(ctypes.c_void_p(y.ctypes.data)))     # not ours to free
+    del xp, rp, sp, gather                                                          # finalizers release the memory
+
+
 def test_channel_bank_config5_shape(pkg):
     """BASELINE.json config 5 in miniature: independent channels, one per visible GPU (two on GPU 0 when
     the box has one), N = 2^20, rows appended on the device, decimated host gather; each channel equals

@@ -32,12 +32,11 @@ for name, nfft, n_frames, stride in cfgs:
     # rows sampled for the bit comparison: first, last, and a stride through the middle
     pick = sorted(set([0, 1, n_frames - 1] + list(range(0, n_frames, max(1, n_frames // 61)))))
     for sp in splits:
-        for k in ("SDRK_OVERLAP", "SDRK_OVL_COL_CUS", "SDRK_OVL_ROW_CUS"):
+        for k in ("SDRK_OVL_COL_CUS", "SDRK_OVL_ROW_CUS"):
             os.environ.pop(k, None)
         if sp is not None:
-            os.environ["SDRK_OVERLAP"] = "1"
             os.environ["SDRK_OVL_COL_CUS"], os.environ["SDRK_OVL_ROW_CUS"] = str(sp[0]), str(sp[1])
-        with SpectrumPlan(nfft, window="hann", device=dev) as plan:
+        with SpectrumPlan(nfft, window="hann", device=dev, overlap_passes=sp is not None) as plan:
             plan.exec_device(d_gen.value, n_frames, d_out.value, frame_stride=stride)
             plan.sync()
             ms = plan.exec_device_timed_each(d_gen.value, n_frames, d_out.value, 9, frame_stride=stride)
