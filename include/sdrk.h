@@ -202,7 +202,7 @@ int sdrk_exec_device_timed_each(sdrk_plan* plan, const void* d_iq_c64, size_t n_
  *   "measured-copy" ceiling SURVEY.md §8(d) asks to be reported next to the nominal 8 TB/s.
  * sdrk_copy_probe: a plain 1:1 copy of `bytes` (16 bytes per lane each way, non-temporal) from d_in to
  *   d_out, timed per launch — the shape MI355X_MICROARCH.md quotes 6.29 TB/s for; run on the same buffers it
- *   anchors the 2:1 probe above to a published figure.  Bandwidth = 2 * bytes / time.
+ *   anchors the 2:1 probe above to a published figure (fastest of three grid sizes).  Bandwidth = 2 * bytes / time.
  * sdrk_host_link_probe: pinned-memory DMA rates in GB/s — `bytes` host-to-device, bytes/2
  *   device-to-host, and both at once (quoted on the upstream bytes): what the numpy
  *   boundary could reach at best.

@@ -139,9 +139,10 @@ hipError_t launch_stream_mix(const void* d_in, void* d_out, size_t n_frames4096,
 }
 
 // The guide's reference shape for "achievable HBM bandwidth": a 1:1 copy, 16 bytes per lane each way
-// (MI355X_MICROARCH.md quotes 6.29 TB/s for it).  Grid-stride over a fixed grid of 8 workgroups per CU, four
+// (MI355X_MICROARCH.md quotes 6.29 TB/s for it).  Grid-stride over a fixed grid of a few workgroups per CU, four
 // independent 16-byte loads per thread in flight.  bench.py runs it on the timed run's own buffers so that the
-// 2:1 probe above can be anchored to a number somebody else measured.
+// 2:1 probe above can be anchored to a number somebody else measured.  The grid size matters by ~6 % (round 1's
+// streambench: 4 or 16 workgroups per CU 5.5 TB/s, 8 per CU 5.2 on 32 + 16 GiB), so the probe tries several.
 __global__ __launch_bounds__(256) void copy_1to1_kernel(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n_vec) {
     const size_t stride = (size_t)gridDim.x * 256 * 4;
     for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n_vec; i += stride) {
@@ -155,11 +156,11 @@ __global__ __launch_bounds__(256) void copy_1to1_kernel(const v4f* __restrict__ 
     }
 }
 
-hipError_t launch_copy_1to1(const void* d_in, void* d_out, size_t bytes, int num_cus, hipStream_t stream) {
+hipError_t launch_copy_1to1(const void* d_in, void* d_out, size_t bytes, int num_cus, int blocks_per_cu, hipStream_t stream) {
     const size_t n_vec = bytes / 16;
     if (n_vec == 0) return hipSuccess;
     size_t blocks = (n_vec + 1023) / 1024;
-    if (blocks > (size_t)num_cus * 8) blocks = (size_t)num_cus * 8;
+    if (blocks > (size_t)num_cus * blocks_per_cu) blocks = (size_t)num_cus * blocks_per_cu;
     hipLaunchKernelGGL(copy_1to1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const v4f*>(d_in),
                        static_cast<v4f*>(d_out), n_vec);
     return hipGetLastError();

@@ -109,7 +109,7 @@ hipError_t launch_row_peaks(const float* d_rows, size_t n_rows, int nfft, const 
 hipError_t launch_decimate_rows(const float* d_ring, int nfft, int maxlen, int start_slot, int n_rows, int factor,
                                 int mode, float* d_out, hipStream_t stream);
 hipError_t launch_stream_mix(const void* d_in, void* d_out, size_t n_frames4096, int num_cus, hipStream_t stream);
-hipError_t launch_copy_1to1(const void* d_in, void* d_out, size_t bytes, int num_cus, hipStream_t stream);
+hipError_t launch_copy_1to1(const void* d_in, void* d_out, size_t bytes, int num_cus, int blocks_per_cu, hipStream_t stream);
 hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,
                              hipStream_t stream);
 

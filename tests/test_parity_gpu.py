@@ -735,6 +735,40 @@ def test_row_features_special_rows(pkg):
     assert got["adaptive_threshold_db"] == ref["adaptive_threshold_db"]
 
 
+def test_peak_scan_every_spacing(pkg):
+    """classifier.py:200-212 for spacings on both sides of the speculative-parallel scan's limit (min_distance <= 16 runs
+    it, larger ones the scalar recurrence) and row lengths that leave the last 64-bin word partly empty: the accepted
+    indices must equal the literal loop's, for noise rows (hundreds of accepted peaks) and a sparse row."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, features
+    lib = _ffi.lib()
+    rng = np.random.default_rng(23)
+
+    def greedy(x, thr, d):
+        out, last = [], -d
+        for i in range(1, len(x) - 1):
+            if float(x[i]) > thr and x[i] > x[i - 1] and x[i] > x[i + 1] and i - last >= d:
+                out.append(i)
+                last = i
+        return out
+
+    for n in (4096, 4000, 1000, 130, 64):
+        rows = (rng.standard_normal((3, n)) * 6).astype(np.float32)
+        rows[2] = -50.0
+        rows[2, rng.integers(1, n - 1, 5)] = 10.0                       # a sparse row: a handful of isolated peaks
+        for d in (1, 2, 3, 13, 16, 17, 40):
+            cap = n
+            stats = np.empty((3, 16)); thr = np.empty(3); idx = np.empty((3, cap), dtype=np.int32); cnt = np.empty(3, dtype=np.int32)
+            _ffi.check(lib.sdrk_row_features(0, rows.ctypes.data_as(ctypes.c_void_p), 0, 3, n, features.percentile_rank(n, 20.0),
+                                             ctypes.c_float(float(features.percentile_gamma(n, 20.0))), d, cap,
+                                             stats.ctypes.data_as(ctypes.c_void_p), thr.ctypes.data_as(ctypes.c_void_p),
+                                             idx.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
+            for r in range(3):
+                want = greedy(rows[r], float(thr[r]), d)
+                assert int(cnt[r]) == len(want), (n, d, r)
+                assert idx[r, : len(want)].tolist() == want, (n, d, r)
+
+
 def test_waterfall_decimated_readout(pkg):
     """f4 (build-side extension): device max-hold / mean decimation of ring rows before D2H."""
     rng = np.random.default_rng(31)

@@ -3,31 +3,61 @@
 #   tools/collect_round.sh r02
 # -> gpurun_out/collect_<tag>/ : rocprofv3 evidence (tools/profile_round.sh), the bench line, the size sweep,
 #    the placement probes and N bench processes with and without placement tuning.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/collect_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 echo "== bench (full line)"; python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "== profiles"; bash tools/profile_round.sh $TAG > "$OUT/profile_round.log" 2>&1; cp gpurun_out/prof_$TAG/summary.json "$OUT/rocprof_summary.json"; cp gpurun_out/prof_$TAG/pmc_fetch_write_rows.csv "$OUT/" 2>/dev/null
-for t in bench cfg3 cfg5; do cp gpurun_out/prof_$TAG/${t}_trace/*/*kernel_stats.csv "$OUT/${t}_kernel_stats.csv" 2>/dev/null; done
+for t in bench cfg3 cfg5 n16384 n2p21 n2p22 feat; do cp gpurun_out/prof_$TAG/${t}_trace/*/*kernel_stats.csv "$OUT/${t}_kernel_stats.csv" 2>/dev/null; done
 echo "== size sweep"; python3 tools/size_sweep.py > "$OUT/size_sweep.log" 2>&1
 echo "== placement probes"
 mkdir -p sdr-iq-visualizer_amd/build_tools
 for t in placeprobe queueprobe; do hipcc --offload-arch=gfx950 -O3 -o sdr-iq-visualizer_amd/build_tools/$t sdr-iq-visualizer_amd/csrc/tools/$t.hip 2>/dev/null; done
 { for i in 1 2 3; do ./sdr-iq-visualizer_amd/build_tools/placeprobe 20 3; done; for i in 1 2 3 4; do ./sdr-iq-visualizer_amd/build_tools/queueprobe 19 4; done; } > "$OUT/placeprobe.log" 2>&1
-echo "== 16 bench processes with placement tuning, 8 without"
+echo "== 12 bench processes with placement tuning, 6 without"
 summ() { python3 -c "
 import json,sys
 l=json.loads(sys.stdin.read()); t=l['telemetry']
 print('%.4f  %.4f  %.4f  %.4f  %7.1f  %.4f  sclk_after %s  probe_ms %s chosen %d' % (l['launch_ms']['median'], l['launch_ms']['min'], l['launch_ms']['max'], l['roofline']['frac'], l['roofline']['measured_copy_GBps'], l['roofline']['frac_of_measured_copy'], t['after']['sclk_mhz'], l['placement']['probe_ms'], l['placement']['chosen']))"; }
-{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   (16 processes; placement: 6 candidates)";
+{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   (12 processes; placement: 6 candidates)";
   echo "# launch_ms median  min  max  frac_of_8TB/s  copy_GB/s  kernel/copy";
-  for i in $(seq 16); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 2>/dev/null | tail -1 | summ; done; } > "$OUT/placement_16_runs.txt"
-{ echo "# the same with --placement-candidates 1 (plain alloc(in); alloc(out)), 8 processes";
-  for i in $(seq 8); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 --placement-candidates 1 2>/dev/null | tail -1 | summ; done; } > "$OUT/plain_alloc_8_runs.txt"
+  for i in $(seq 12); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 2>/dev/null | tail -1 | summ; done; } > "$OUT/placement_runs.txt"
+{ echo "# the same with --placement-candidates 1 (plain alloc(in); alloc(out)), 6 processes";
+  for i in $(seq 6); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 --placement-candidates 1 2>/dev/null | tail -1 | summ; done; } > "$OUT/plain_alloc_runs.txt"
 echo "== fused vs tiled N=65536 (4096 packed frames, then config 3; Hann)"
 { python3 tools/fused_probe.py 4096 65536 hann; python3 tools/fused_probe.py 18749 32768 hann; } > "$OUT/fused64k_vs_tiled.log" 2>&1
-cat "$OUT/fused64k_vs_tiled.log"; tail -3 "$OUT/placement_16_runs.txt"; tail -3 "$OUT/plain_alloc_8_runs.txt"
+cat "$OUT/fused64k_vs_tiled.log"; tail -3 "$OUT/placement_runs.txt"; tail -3 "$OUT/plain_alloc_runs.txt"
+echo "== overlap of the two large-frame passes (SDRK_PLAN_OVERLAP_PASSES): sweep, then kernel traces"
+timeout -k 10 400 python3 tools/overlap_probe.py both > "$OUT/overlap_probe.log" 2>&1; tail -4 "$OUT/overlap_probe.log"
+( cd /tmp && export TMPDIR=/tmp
+  for cfg in cfg3 cfg5; do for mode in serial overlap; do
+    rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_${cfg}_$mode" -- python3 "$ROOT/tools/overlap_trace.py" $cfg $mode 2> /dev/null
+    python3 "$ROOT/tools/summarise_overlap_trace.py" "$OUT/trace_${cfg}_$mode" "$cfg $mode"
+  done; done ) > "$OUT/overlap_trace_summary.txt" 2>&1
+cp "$OUT"/trace_cfg3_overlap/*/*kernel_trace.csv "$OUT/cfg3_overlap_kernel_trace.csv" 2>/dev/null
+python3 - "$OUT/cfg3_overlap_kernel_trace.csv" <<'PY'
+# keep the trace small enough to commit: the pass kernels of the last launch only, name shortened
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "_pass_" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[-2 * 98:]
+t0 = int(rows[0]["Start_Timestamp"])
+with open(sys.argv[1], "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["kernel", "queue_id", "start_us", "end_us", "grid", "workgroup"])
+    for r in rows:
+        w.writerow(["col_pass" if "col_pass" in r["Kernel_Name"] else "row_pass", r.get("Queue_Id", ""),
+                    round((int(r["Start_Timestamp"]) - t0) / 1e3, 2), round((int(r["End_Timestamp"]) - t0) / 1e3, 2),
+                    r.get("Grid_Size", ""), r.get("Workgroup_Size", "")])
+PY
+rm -rf "$OUT"/trace_*/
+cat "$OUT/overlap_trace_summary.txt"
+echo "== host link: pageable / registered / pinned copies of 1 GiB in + 0.5 GiB out"
+mkdir -p sdr-iq-visualizer_amd/build_tools
+hipcc --offload-arch=gfx950 -O3 -o sdr-iq-visualizer_amd/build_tools/pcie_probe sdr-iq-visualizer_amd/csrc/tools/pcie_probe.hip 2>/dev/null && ./sdr-iq-visualizer_amd/build_tools/pcie_probe > "$OUT/pcie_probe.log" 2>&1; cat "$OUT/pcie_probe.log"
+echo "== bench.py --gpus 2, self-launched (rehearsal on one GPU: gloo rendezvous, ranks share the device)"
+python3 bench.py --gpus 2 --steps 3 --warmup 1 --frames 262144 --cpu-seconds 3 --cpu-all-cores-seconds 2 2> "$OUT/bench_gpus2_rehearsal.err" | grep '^{' > "$OUT/bench_gpus2_rehearsal.json"; echo "rc=$? $(wc -c < "$OUT/bench_gpus2_rehearsal.json") bytes"
 echo "== one-frame host call"; python3 tools/small_call_probe.py > "$OUT/small_call_probe.log" 2>&1; cat "$OUT/small_call_probe.log"
 echo "== gpu tests"; python3 -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -2 "$OUT/pytest_gpu.log"

@@ -39,9 +39,30 @@ def pmc(dirname, counter):
     return {k: {"dispatches": len(v), "mean_KB": sum(v) / len(v), "sum_KB": sum(v)} for k, v in acc.items()}
 
 
+def tags(root):
+    """Every <tag>_trace directory of the collection, the BASELINE ones first."""
+    found = sorted(os.path.basename(d)[:-6] for d in glob.glob(os.path.join(root, "*_trace")) if os.path.isdir(d))
+    first = [t for t in ("bench", "cfg3", "cfg5") if t in found]
+    return first + [t for t in found if t not in first]
+
+
+def sq(root, tag):
+    """SQ counters of the <tag>_sq* passes: per kernel the mean per dispatch."""
+    acc = defaultdict(lambda: defaultdict(list))
+    for d in sorted(glob.glob(os.path.join(root, f"{tag}_sq*"))):
+        for f in newest(d, "*counter_collection.csv"):
+            per = defaultdict(float)
+            for row in csv.DictReader(open(f)):
+                per[(row["Dispatch_Id"], short(row["Kernel_Name"]), row["Counter_Name"])] += float(row["Counter_Value"])
+            for (_, k, c), v in per.items():
+                acc[k][c].append(v)
+    return {k: {c: round(sum(v) / len(v)) for c, v in sorted(cs.items())} | {"dispatches": max(len(v) for v in cs.values())}
+            for k, cs in acc.items() if k.startswith(("fft4096", "row_"))}
+
+
 def main(root):
     res = {}
-    for tag in ("bench", "cfg3", "cfg5"):
+    for tag in tags(root):
         st, fe, wr = stats(f"{root}/{tag}_trace"), pmc(f"{root}/{tag}_fetch", "FETCH_SIZE"), pmc(f"{root}/{tag}_write", "WRITE_SIZE")
         kernels = {}
         for k in sorted(set(st) | set(fe) | set(wr)):
@@ -54,6 +75,9 @@ def main(root):
                 rec["WRITE_SIZE_KB_mean"] = round(wr[k]["mean_KB"], 3)
                 rec["write_bytes_per_dispatch"] = round(wr[k]["mean_KB"] * 1024)
             kernels[k] = rec
+        counters = sq(root, tag)
+        for k, c in counters.items():
+            kernels.setdefault(k, {})["sq_counters_mean_per_dispatch"] = c
         res[tag] = kernels
     print(json.dumps(res, indent=1))
 
@@ -65,7 +89,7 @@ def rows(root, out_csv):
     with open(out_csv, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(cols)
-        for tag in ("bench", "cfg3", "cfg5"):
+        for tag in tags(root):
             for kind in ("fetch", "write"):
                 for f in newest(f"{root}/{tag}_{kind}", "*counter_collection.csv"):
                     for r in csv.DictReader(open(f)):
