@@ -76,7 +76,6 @@ hipError_t launch_fft4096(const LaunchArgs& a);
 hipError_t launch_fft_small(const LaunchArgs& a);   // 2 <= nfft <= 2048: Stockham radix-2 in LDS (N = 2, 4, 8 and far-apart frames)
 bool fft_lds_supports(int nfft);                     // 16 .. 16384 except 4096: registers + LDS, one pass over HBM
 hipError_t launch_fft_lds(const LaunchArgs& a);
-hipError_t launch_fft_lds32k(const LaunchArgs& a);  // 32768: registers + a float-plane LDS exchange, one pass over HBM (fft_lds32k.hip)
 bool fft_tiled2_split(int nfft, int* log2a, int* log2m);   // 2^15 .. 2^22: N = A * M, both in LDS
 hipError_t launch_fft_tiled2(const LaunchArgs& a);
 hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,

@@ -229,8 +229,6 @@ int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_st
         e = sdrk::launch_fft4096(a);
     else if (sdrk::fft_lds_supports(p->nfft))
         e = sdrk::launch_fft_lds(a);
-    else if (p->nfft == 32768 && !p->tiled2)
-        e = sdrk::launch_fft_lds32k(a);
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
     else if (p->fused64k) {
@@ -437,7 +435,7 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
     // Caller arrays in pinned memory (sdrk_host_alloc / sdrk_host_register) are not staged: the copy engines read
     // and write them directly.  Decided per side.
     const bool in_pinned = pinned_ranges().covers(iq, in_bytes), out_pinned = pinned_ranges().covers(out, out_bytes);
-    const bool zero_copy = !p->tiled2 && p->nfft <= 32768 && !p->blu_inner && frame_stride >= nfft && in_bytes <= ZERO_COPY_MAX_BYTES &&
+    const bool zero_copy = p->nfft <= 16384 && !p->blu_inner && frame_stride >= nfft && in_bytes <= ZERO_COPY_MAX_BYTES &&
                            !in_pinned && !out_pinned;
     const double t_call = tr.on ? HostTrace::now() : 0;
     size_t c = 0;
@@ -861,14 +859,10 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
         *out = p;
         return SDRK_OK;
     }
-    // twiddles of the in-LDS transform: W_N for N <= 32768 (fft4096.hip, fft_lds.hip, fft_lds32k.hip, fft_small.hip);
-    // the two-pass plans carry their own tables below
-#ifdef SDRK_32K_TILED
-    constexpr int ONE_PASS_MAX = 16384;   // (A/B build: N = 32768 through the two tiled passes, as in round 2)
-#else
-    constexpr int ONE_PASS_MAX = 32768;
-#endif
-    if (nfft <= ONE_PASS_MAX) {
+    // twiddles of the in-LDS transform: W_N for N <= 16384 (fft4096.hip, fft_lds.hip, fft_small.hip); the
+    // two-pass plans carry their own tables below.  (N = 32768 also fits one CU — 32 points per thread, float-plane
+    // LDS exchanges — and was built and measured in round 3: no faster than the two passes)
+    if (nfft <= 16384) {
         std::vector<float2> t(nfft);
         for (int m = 0; m < nfft; ++m) t[m] = twiddle(m, nfft);
         PLAN_TRY(hipMalloc((void**)&p->d_twiddle, sizeof(float2) * nfft));
