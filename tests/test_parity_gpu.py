@@ -769,6 +769,14 @@ def test_peak_scan_every_spacing(pkg):
                 assert idx[r, : len(want)].tolist() == want, (n, d, r)
 
 
+def test_row_features_randomised(pkg):
+    """tools/stress_features.py with a fixed seed: 96 random rows (lengths 64 ... 40000; smooth noise, heavy ties, far-off
+    percentiles, -inf bins, plateaus) through the per-row reductions, every exact quantity equal to the oracle's."""
+    from tools import stress_features
+    done = stress_features.run(96, 5)
+    assert sum(done.values()) == 96 and min(done.values()) == 12
+
+
 def test_waterfall_decimated_readout(pkg):
     """f4 (build-side extension): device max-hold / mean decimation of ring rows before D2H."""
     rng = np.random.default_rng(31)
@@ -887,7 +895,7 @@ def test_pinned_host_arrays_are_not_staged(pkg):
     import ctypes
     from sdr_iq_visualizer_amd import _ffi
     rng = np.random.default_rng(12)
-    for n, b in ((4096, 3000), (4096, 100), (16384, 700), (65536, 40)):
+    for n, b in ((4096, 3000), (4096, 100), (4096, 2), (16384, 700), (65536, 40), (1000, 50), (1 << 20, 3)):
         x = rand_c64(rng, b, n, scale=20.0)
         ref = pkg.spectrum_db(x)                                  # pageable in, pageable out
         xp = pkg.pinned_empty((b, n), np.complex64)
