@@ -438,6 +438,18 @@ def feature_reductions(lib, _ffi, SpectrumPlan, features, dev, n_frames=1 << 18)
                                                  max(3, n // 300), max_peaks, hp["stats"], hp["thr"], hp["idx"], hp["cnt"]))
 
             t = timed(separate)
+            # at-scale consistency: the fused epilogue and the stand-alone kernel run the same routine on the same row
+            # values, so their results must agree on every one of the rows (statistics, threshold, peak list)
+            fused(bufs["rows"])
+            chk = {"stats": np.empty_like(host["stats"]), "thr": np.empty_like(host["thr"]), "idx": np.empty_like(host["idx"]),
+                   "cnt": np.empty_like(host["cnt"])}
+            for k in chk:
+                _ffi.check(lib.sdrk_memcpy_d2h(dev, chk[k].ctypes.data_as(ctypes.c_void_p), bufs[k], chk[k].nbytes))
+            kept = np.minimum(host["cnt"], max_peaks)[:, None] > np.arange(max_peaks)[None, :]
+            out["fused_equals_stand_alone_on_all_rows"] = bool(
+                np.array_equal(chk["stats"], host["stats"]) and np.array_equal(chk["thr"], host["thr"]) and
+                np.array_equal(chk["cnt"], host["cnt"]) and np.array_equal(chk["idx"][kept], host["idx"][kept]))
+            out["peaks_per_row_mean"] = round(float(host["cnt"].mean()), 1)
             out["transform_then_single_read_reduction"] = {
                 "ms": round(t * 1e3, 3), "rows_per_s": round(n_frames / t),
                 "what": "fft4096_kernel writes the rows, row_features_kernel reads them once (staged in LDS); "
