@@ -355,7 +355,7 @@ def numpy_boundary(lib, _ffi, pkg, synth, dev):
             rec["reused_out_ms_per_call"] = round(_median(ts) * 1e3, 4)
             rec["reused_out_input_GBps"] = round(bsz * NFFT * 8 / _median(ts) / 1e9, 2)
             rec["reused_out_frac_of_duplex_link"] = round(bsz * NFFT * 8 / _median(ts) / 1e9 / c.value, 3)
-        if bsz >= 4096:                                         # input and result in pinned arrays: no staging copies
+        if bsz >= 256:                                          # input and result in pinned arrays: no staging copies
             xp, rp = pkg.pinned_empty(x.shape, np.complex64), pkg.pinned_empty(x.shape, np.float32)
             xp[...] = x
             pkg.spectrum_db(xp, device=dev, out=rp)

@@ -437,6 +437,19 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
     const bool in_pinned = pinned_ranges().covers(iq, in_bytes), out_pinned = pinned_ranges().covers(out, out_bytes);
     const bool zero_copy = p->nfft <= 16384 && !p->blu_inner && frame_stride >= nfft && in_bytes <= ZERO_COPY_MAX_BYTES &&
                            !in_pinned && !out_pinned;
+    if (in_pinned && out_pinned && p->nfft <= 16384 && !p->blu_inner && frame_stride >= nfft && in_bytes <= ZERO_COPY_MAX_BYTES) {
+        // both arrays pinned, a call small enough that the link's latency matters more than its last 10 %: ONE launch
+        // that reads the caller's frames and writes the caller's rows over PCIe — no staging, no copy engine, no chunks
+        void *d_src = nullptr, *d_dst = nullptr;
+        if (hipHostGetDevicePointer(&d_src, const_cast<void*>(iq), 0) == hipSuccess &&
+            hipHostGetDevicePointer(&d_dst, out, 0) == hipSuccess) {
+            st = plan_launch(p, d_src, n_frames, frame_stride, d_dst, epilogue, p->stream);
+            if (st != SDRK_OK) return st;
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            return fused_check(p);
+        }
+        (void)hipGetLastError();   // no device view of the range: take the copy-engine path below
+    }
     const double t_call = tr.on ? HostTrace::now() : 0;
     size_t c = 0;
     for (size_t f0 = 0; f0 < n_frames; f0 += per, ++c) {

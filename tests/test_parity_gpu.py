@@ -901,7 +901,7 @@ def test_pinned_host_arrays_are_not_staged(pkg):
         xp = pkg.pinned_empty((b, n), np.complex64)
         xp[...] = x
         rp = pkg.pinned_empty((b, n), np.float32)
-        assert pkg.is_pinned(xp) and pkg.is_pinned(rp) and pkg.is_pinned(rp[3:7]) and not pkg.is_pinned(x)
+        assert pkg.is_pinned(xp) and pkg.is_pinned(rp) and pkg.is_pinned(rp[b // 2:]) and not pkg.is_pinned(x)
         rp.fill(np.nan)
         assert pkg.spectrum_db(xp, out=rp) is rp and np.array_equal(rp, ref), (n, b, "both pinned")
         assert np.array_equal(pkg.spectrum_db(xp), ref), (n, b, "pinned in")
