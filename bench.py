@@ -288,10 +288,11 @@ def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=16, p
     """BASELINE.json configs[4] as SURVEY.md §8(d) words it, one channel on this GPU: back-to-back N = 2^20 Hann
     frames from a device-resident stream, every row appended to the device waterfall ring (100 x 4 MiB), and after
     each batch of rows a decimated (max-hold to `px` bins) read-out of the new rows to the host."""
+    import numpy as np
     nfft = 1 << 20
     d_in = ctypes.c_void_p()
     _ffi.check(lib.sdrk_dev_alloc(dev, n_frames * nfft * 8, ctypes.byref(d_in)))
-    wf = pkg.WaterfallBuffer(nfft, maxlen=100, device=dev)
+    wf = pkg.WaterfallBuffer(nfft, maxlen=100, device=dev, window="hann")
     try:
         _ffi.check(lib.sdrk_synth_fill(dev, 1234 + dev, 0, n_frames * nfft // 4096, 4096, d_in, None))
         with SpectrumPlan(nfft, window="hann", device=dev) as plan:
@@ -304,12 +305,35 @@ def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=16, p
                                                                   ctypes.c_size_t(batch), ctypes.c_size_t(nfft)))
                     got += wf.as_array(max_rows=batch, decimate=nfft // px).shape[0]
                 return got
+
+            slots = [pkg.pinned_empty((batch, px), np.float32) for _ in range(2)]
+
+            def run_pipelined():
+                # the same work with nothing waited for that does not have to be: batch i + 1 is enqueued before batch
+                # i's rows are collected, so its transform runs while they cross PCIe (two-phase decimated read-out)
+                wf.clear()
+                got, pending = 0, False
+                for i, f0 in enumerate(range(0, n_frames, batch)):
+                    wf.append_iq_device(d_in.value + f0 * nfft * 8, batch, nfft, wait=False)
+                    if pending:
+                        got += wf.gather_end().shape[0]
+                    wf.gather_begin(max_rows=batch, decimate=nfft // px, out=slots[i & 1])
+                    pending = True
+                got += wf.gather_end().shape[0]
+                return got
+
             run()
             ts = []
             for _ in range(5):
                 t0 = time.perf_counter()
                 rows = run()
                 ts.append(time.perf_counter() - t0)
+            run_pipelined()
+            tp = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                rows_p = run_pipelined()
+                tp.append(time.perf_counter() - t0)
     finally:
         wf.close()
         lib.sdrk_dev_free(dev, d_in)
@@ -319,7 +343,12 @@ def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=16, p
             "rows_gathered": rows, "ms": round(t * 1e3, 3), "ms_min": round(min(ts) * 1e3, 3), "ms_max": round(max(ts) * 1e3, 3),
             "Msamples_per_s": round(rate, 1), "realtime_factor_at_61.44_Msps": round(rate / 61.44, 1),
             "realtime_61.44_Msps_holds": bool(rate >= 61.44),
-            "what": "transform -> device waterfall ring -> decimated host gather, host-timed (perf_counter) including every sync"}
+            "what": "transform -> device waterfall ring -> decimated host gather, host-timed (perf_counter) including every sync",
+            "pipelined": {"ms": round(_median(tp) * 1e3, 3), "ms_min": round(min(tp) * 1e3, 3), "ms_max": round(max(tp) * 1e3, 3),
+                          "rows_gathered": rows_p, "Msamples_per_s": round(n_frames * nfft / _median(tp) / 1e6, 1),
+                          "realtime_factor_at_61.44_Msps": round(n_frames * nfft / _median(tp) / 1e6 / 61.44, 1),
+                          "what": "append_iq_device(wait=False) + gather_begin / gather_end into pinned slots: batch i+1's "
+                                  "transform is enqueued before batch i's rows are collected"}}
 
 
 def numpy_boundary(lib, _ffi, pkg, synth, dev):

@@ -290,6 +290,13 @@ int sdrk_waterfall_append_iq(sdrk_waterfall* wf, sdrk_plan* plan, const void* iq
 int sdrk_waterfall_append_iq_device(sdrk_waterfall* wf, sdrk_plan* plan,
                                     const void* d_iq_c64, size_t n_frames,
                                     size_t frame_stride);
+/* The same without waiting: the transforms are only enqueued on the ring's stream.  Every later call on this
+ * waterfall (append, read, read_decimated, sync, destroy) is ordered behind them; d_iq_c64 must stay valid and
+ * unmodified until one of those has returned after waiting (read, read_decimated, _end, sync). */
+int sdrk_waterfall_append_iq_device_async(sdrk_waterfall* wf, sdrk_plan* plan, const void* d_iq_c64,
+                                          size_t n_frames, size_t frame_stride);
+/* Wait for everything enqueued on the ring's stream (`plan`, if not NULL: also report its launches' errors). */
+int sdrk_waterfall_sync(sdrk_waterfall* wf, sdrk_plan* plan);
 /* Number of valid rows (<= maxlen). */
 int sdrk_waterfall_rows(const sdrk_waterfall* wf);
 /* Copy the valid rows, oldest first, into out (capacity max_rows rows); the
@@ -303,6 +310,15 @@ int sdrk_waterfall_read(sdrk_waterfall* wf, float* out, size_t max_rows, size_t*
  * dashboard/callbacks.py:182-190, which is unusable at nfft = 2^20.) */
 int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
                                   size_t* n_rows);
+/* sdrk_waterfall_read_decimated in two halves, for a continuous channel (BASELINE config 5): _begin enqueues the
+ * reduction behind everything appended so far and the device-to-host copy of its result on a second stream, and
+ * returns; _end waits for that copy.  Between the two the caller can enqueue the next batch of frames
+ * (sdrk_waterfall_append_iq_device_async), whose transform then runs while the previous batch's rows cross PCIe.
+ * `out` must stay valid until _end (pinned memory makes the copy truly asynchronous).  One read in flight per
+ * waterfall; n_rows is known at _begin. */
+int sdrk_waterfall_read_decimated_begin(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
+                                        size_t* n_rows);
+int sdrk_waterfall_read_decimated_end(sdrk_waterfall* wf);
 int sdrk_waterfall_clear(sdrk_waterfall* wf);
 
 #ifdef __cplusplus

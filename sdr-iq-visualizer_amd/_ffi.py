@@ -101,6 +101,10 @@ SYMBOLS = [
     ("sdrk_waterfall_append_rows", c_int, [c_void_p, c_void_p, c_size_t]),
     ("sdrk_waterfall_append_iq", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t]),
     ("sdrk_waterfall_append_iq_device", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t]),
+    ("sdrk_waterfall_append_iq_device_async", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t]),
+    ("sdrk_waterfall_sync", c_int, [c_void_p, c_void_p]),
+    ("sdrk_waterfall_read_decimated_begin", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, POINTER(c_size_t)]),
+    ("sdrk_waterfall_read_decimated_end", c_int, [c_void_p]),
     ("sdrk_waterfall_rows", c_int, [c_void_p]),
     ("sdrk_waterfall_read", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]),
     ("sdrk_waterfall_read_decimated", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, POINTER(c_size_t)]),

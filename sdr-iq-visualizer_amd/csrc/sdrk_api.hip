@@ -169,6 +169,10 @@ struct sdrk_waterfall {
     hipStream_t stream = nullptr;
     void* d_dec = nullptr;    // decimated read-out staging (only grows)
     size_t dec_cap = 0;
+    // two-phase decimated read-out: copy stream, "reduction done" event, a read in flight
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_dec = nullptr;
+    bool read_pending = false;
 };
 
 namespace {
@@ -1497,6 +1501,11 @@ int sdrk_waterfall_create(int device, int nfft, int maxlen, sdrk_waterfall** out
 int sdrk_waterfall_destroy(sdrk_waterfall* wf) {
     if (!wf) return SDRK_OK;
     (void)hipSetDevice(wf->device);
+    if (wf->s_copy) {
+        (void)hipStreamSynchronize(wf->s_copy);
+        (void)hipStreamDestroy(wf->s_copy);
+    }
+    if (wf->ev_dec) (void)hipEventDestroy(wf->ev_dec);
     if (wf->stream) {
         (void)hipStreamSynchronize(wf->stream);
         (void)hipStreamDestroy(wf->stream);
@@ -1545,8 +1554,8 @@ int sdrk_waterfall_append_rows(sdrk_waterfall* wf, const float* rows, size_t n_r
     return SDRK_OK;
 }
 
-int sdrk_waterfall_append_iq_device(sdrk_waterfall* wf, sdrk_plan* p, const void* d_iq,
-                                    size_t n_frames, size_t frame_stride) {
+int sdrk_waterfall_append_iq_device_async(sdrk_waterfall* wf, sdrk_plan* p, const void* d_iq,
+                                          size_t n_frames, size_t frame_stride) {
     if (!wf || !p) return fail(SDRK_ERR_INVALID, "waterfall or plan is NULL");
     if (p->nfft != wf->nfft || p->device != wf->device)
         return fail(SDRK_ERR_INVALID, "plan (nfft %d, device %d) does not match waterfall (nfft %d, device %d)",
@@ -1567,8 +1576,21 @@ int sdrk_waterfall_append_iq_device(sdrk_waterfall* wf, sdrk_plan* p, const void
         wf_advance(wf, run);
         done += run;
     }
+    return SDRK_OK;
+}
+
+int sdrk_waterfall_sync(sdrk_waterfall* wf, sdrk_plan* p) {
+    if (!wf) return fail(SDRK_ERR_INVALID, "waterfall is NULL");
+    HIP_TRY(hipSetDevice(wf->device));
     HIP_TRY(hipStreamSynchronize(wf->stream));
-    return fused_check(p);
+    return p ? fused_check(p) : SDRK_OK;
+}
+
+int sdrk_waterfall_append_iq_device(sdrk_waterfall* wf, sdrk_plan* p, const void* d_iq,
+                                    size_t n_frames, size_t frame_stride) {
+    int st = sdrk_waterfall_append_iq_device_async(wf, p, d_iq, n_frames, frame_stride);
+    if (st != SDRK_OK || n_frames == 0) return st;
+    return sdrk_waterfall_sync(wf, p);
 }
 
 int sdrk_waterfall_append_iq(sdrk_waterfall* wf, sdrk_plan* p, const void* iq, size_t n_frames,
@@ -1614,6 +1636,7 @@ int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_row
     *n_rows = 0;
     if (factor < 1 || wf->nfft % factor != 0) return fail(SDRK_ERR_INVALID, "factor %d must divide nfft %d", factor, wf->nfft);
     if (mode != 0 && mode != 1) return fail(SDRK_ERR_INVALID, "mode must be 0 (max) or 1 (mean)");
+    if (wf->read_pending) return fail(SDRK_ERR_INVALID, "a two-phase decimated read is in flight (call _end first)");
     size_t rows = wf->count < max_rows ? wf->count : max_rows;
     if (rows == 0) return SDRK_OK;
     if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
@@ -1629,6 +1652,46 @@ int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_row
     HIP_TRY(hipMemcpyAsync(out, wf->d_dec, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->stream));
     HIP_TRY(hipStreamSynchronize(wf->stream));
     *n_rows = rows;
+    return SDRK_OK;
+}
+
+int sdrk_waterfall_read_decimated_begin(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
+                                        size_t* n_rows) {
+    if (!wf || !n_rows) return fail(SDRK_ERR_INVALID, "waterfall or n_rows is NULL");
+    *n_rows = 0;
+    if (wf->read_pending) return fail(SDRK_ERR_INVALID, "a decimated read is already in flight (call _end first)");
+    if (factor < 1 || wf->nfft % factor != 0) return fail(SDRK_ERR_INVALID, "factor %d must divide nfft %d", factor, wf->nfft);
+    if (mode != 0 && mode != 1) return fail(SDRK_ERR_INVALID, "mode must be 0 (max) or 1 (mean)");
+    size_t rows = wf->count < max_rows ? wf->count : max_rows;
+    if (rows == 0) return SDRK_OK;
+    if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
+    HIP_TRY(hipSetDevice(wf->device));
+    if (!wf->s_copy) {
+        HIP_TRY(hipStreamCreateWithFlags(&wf->s_copy, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&wf->ev_dec, hipEventDisableTiming));
+    }
+    const size_t L = (size_t)wf->maxlen;
+    const size_t start = (wf->head + L - rows % L) % L;
+    const size_t bins = (size_t)(wf->nfft / factor);
+    int st = grow(wf->device, &wf->d_dec, &wf->dec_cap, rows * bins * sizeof(float));
+    if (st != SDRK_OK) return st;
+    hipError_t e = sdrk::launch_decimate_rows(wf->d_ring, wf->nfft, wf->maxlen, (int)start, (int)rows, factor, mode,
+                                              static_cast<float*>(wf->d_dec), wf->stream);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "decimate launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(wf->ev_dec, wf->stream));
+    HIP_TRY(hipStreamWaitEvent(wf->s_copy, wf->ev_dec, 0));
+    HIP_TRY(hipMemcpyAsync(out, wf->d_dec, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->s_copy));
+    wf->read_pending = true;
+    *n_rows = rows;
+    return SDRK_OK;
+}
+
+int sdrk_waterfall_read_decimated_end(sdrk_waterfall* wf) {
+    if (!wf) return fail(SDRK_ERR_INVALID, "waterfall is NULL");
+    if (!wf->read_pending) return SDRK_OK;
+    HIP_TRY(hipSetDevice(wf->device));
+    wf->read_pending = false;
+    HIP_TRY(hipStreamSynchronize(wf->s_copy));
     return SDRK_OK;
 }
 

@@ -47,7 +47,8 @@ class WaterfallBuffer:
     def close(self) -> None:
         h, self._handle = self._handle, c_void_p()
         if h:
-            lib().sdrk_waterfall_destroy(h)
+            lib().sdrk_waterfall_destroy(h)       # (waits for a copy that gather_begin may have left in flight)
+        self._gather = None
         if self._plan is not None:
             self._plan.close()
             self._plan = None
@@ -111,11 +112,57 @@ class WaterfallBuffer:
         if n_frames == 0:
             return
         with self._lock:
-            if self._plan is None:
-                self._plan = SpectrumPlan(self.nfft, window=self._window, eps=self._eps, shift=True,
-                                          device=self.device)
-            check(lib().sdrk_waterfall_append_iq(self._h(), self._plan.handle, x.ctypes.data_as(c_void_p),
+            check(lib().sdrk_waterfall_append_iq(self._h(), self._ensure_plan().handle, x.ctypes.data_as(c_void_p),
                                                  c_size_t(n_frames), c_size_t(stride)))
+
+    # -- a continuous channel whose IQ is already on the device (BASELINE config 5) ---------------
+    def _ensure_plan(self) -> SpectrumPlan:
+        if self._plan is None:
+            self._plan = SpectrumPlan(self.nfft, window=self._window, eps=self._eps, shift=True, device=self.device)
+        return self._plan
+
+    def append_iq_device(self, d_iq: int, n_frames: int, frame_stride: Optional[int] = None, *, wait: bool = True) -> None:
+        """Transform ``n_frames`` frames of device-resident complex64 IQ (device pointer ``d_iq``) straight into the
+        ring.  ``wait=False`` only enqueues the work on the ring's stream: the next read / ``sync()`` is ordered behind
+        it, and the IQ buffer must stay untouched until then."""
+        stride = self.nfft if frame_stride is None else int(frame_stride)
+        with self._lock:
+            fn = lib().sdrk_waterfall_append_iq_device if wait else lib().sdrk_waterfall_append_iq_device_async
+            check(fn(self._h(), self._ensure_plan().handle, c_void_p(int(d_iq)), c_size_t(int(n_frames)), c_size_t(stride)))
+
+    def sync(self) -> None:
+        with self._lock:
+            check(lib().sdrk_waterfall_sync(self._h(), self._plan.handle if self._plan is not None else None))
+
+    def gather_begin(self, max_rows: Optional[int] = None, *, decimate: int = 1, mode: str = "max",
+                     out: Optional[np.ndarray] = None) -> np.ndarray:
+        """First half of a decimated read-out: the reduction is enqueued behind everything appended so far and its
+        result starts crossing PCIe on a second stream; returns the (not yet filled) ``(rows, nfft // decimate)`` array.
+        Call ``gather_end()`` before using it.  Between the two, ``append_iq_device(..., wait=False)`` of the next
+        batch overlaps this batch's copy.  ``out``: a float32 array (ideally ``pinned_empty``) with room for the rows."""
+        if mode not in ("max", "mean"):
+            raise ValueError("mode must be 'max' or 'mean'")
+        if decimate < 1 or self.nfft % decimate:
+            raise ValueError(f"decimate={decimate} must divide nfft={self.nfft}")
+        with self._lock:
+            rows = len(self) if max_rows is None else min(len(self), int(max_rows))
+            bins = self.nfft // decimate
+            if out is None:
+                out = np.empty((rows, bins), dtype=np.float32)
+            elif out.dtype != np.float32 or not out.flags.c_contiguous or out.ndim != 2 or out.shape[1] != bins or out.shape[0] < rows:
+                raise ValueError(f"out must be a C-contiguous float32 array of at least ({rows}, {bins})")
+            got = c_size_t(0)
+            check(lib().sdrk_waterfall_read_decimated_begin(self._h(), out.ctypes.data_as(c_void_p), c_size_t(rows),
+                                                            int(decimate), 0 if mode == "max" else 1, byref(got)))
+            self._gather = out[: got.value]          # keeps the array alive until gather_end()
+            return self._gather
+
+    def gather_end(self) -> Optional[np.ndarray]:
+        """Second half: wait for the copy started by ``gather_begin`` and return its array."""
+        with self._lock:
+            check(lib().sdrk_waterfall_read_decimated_end(self._h()))
+            g, self._gather = getattr(self, "_gather", None), None
+            return g
 
     def as_array(self, max_rows: Optional[int] = None, *, decimate: int = 1, mode: str = "max") -> np.ndarray:
         """``np.array(deque)``: float32 ``(rows, nfft)``, oldest row at index 0.  With

@@ -777,6 +777,53 @@ def test_row_features_randomised(pkg):
     assert sum(done.values()) == 96 and min(done.values()) == 12
 
 
+def test_waterfall_async_append_and_two_phase_gather(pkg):
+    """A continuous channel with nothing waited for that does not have to be (BASELINE config 5): appends that are
+    only enqueued, decimated read-outs in two halves into pinned slots, the next batch enqueued in between.  Every
+    gathered batch must equal the blocking form's, and the ring afterwards the oracle's rows."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, synth
+    lib = _ffi.lib()
+    n, batch, nb, f = 65536, 3, 5, 16
+    x = synth.synth_iq(9, 0, nb * batch * n // 4096, 4096).reshape(nb * batch, n)
+    d_in = ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, x.nbytes, ctypes.byref(d_in)))
+    _ffi.check(lib.sdrk_memcpy_h2d(0, d_in, x.ctypes.data_as(ctypes.c_void_p), x.nbytes))
+    wf = pkg.WaterfallBuffer(n, maxlen=7, window="hann")
+    ref = pkg.WaterfallBuffer(n, maxlen=7, window="hann")
+    try:
+        blocking = []
+        for b in range(nb):
+            ref.append_iq_device(d_in.value + b * batch * n * 8, batch)
+            blocking.append(ref.as_array(max_rows=batch, decimate=f))
+        slots = [pkg.pinned_empty((batch, n // f), np.float32) for _ in range(2)]
+        got, pending = [], False
+        for b in range(nb):
+            wf.append_iq_device(d_in.value + b * batch * n * 8, batch, wait=False)
+            if pending:
+                got.append(wf.gather_end().copy())
+            with pytest.raises(ValueError):
+                wf.gather_begin(max_rows=batch, decimate=f, out=np.empty((1, 3), np.float32))
+            wf.gather_begin(max_rows=batch, decimate=f, out=slots[b & 1])
+            pending = True
+            with pytest.raises(ValueError):                       # one read in flight per waterfall
+                wf.gather_begin(max_rows=batch, decimate=f)
+            with pytest.raises(ValueError):
+                wf.as_array(decimate=f)
+        got.append(wf.gather_end().copy())
+        assert wf.gather_end() is None                           # nothing in flight any more
+        for b in range(nb):
+            assert np.array_equal(got[b], blocking[b]), b
+        wf.sync()
+        assert len(wf) == 7
+        assert_db_parity(wf.as_array(), cpu_ref.spectrum_db(x[-7:], window=np.hanning(n)), what="ring after async appends")
+        assert np.array_equal(wf.as_array(), ref.as_array())
+    finally:
+        wf.close()
+        ref.close()
+        lib.sdrk_dev_free(0, d_in)
+
+
 def test_waterfall_decimated_readout(pkg):
     """f4 (build-side extension): device max-hold / mean decimation of ring rows before D2H."""
     rng = np.random.default_rng(31)
