@@ -77,29 +77,6 @@ __device__ __forceinline__ unsigned long long rf_clear_below(unsigned long long 
     return n <= 0 ? m : (n >= 64 ? 0ull : m & (~0ull << n));
 }
 
-// 10^(v/10) in double to ~1e-11 relative (the sums it feeds are compared at 1e-9): 2^t with t = v log2(10)/10
-// split into an integer and a fraction in [-1/2, 1/2], degree-10 Taylor polynomial of e^(f ln 2), v_ldexp_f64.
-// libm's pow() + log() per element (the literal restatement) cost ~6x this; ln p needs no transcendental at all:
-// ln(10^(v/10)) = v ln(10)/10.
-__device__ __forceinline__ double rf_pow10_tenth(double v) {
-    const double t = v * 0.33219280948873623479;   // log2(10) / 10
-    const double k = rint(t);
-    const double g = (t - k) * 0.69314718055994530942;
-    double p = 2.7557319223985890653e-07;           // 1/10!
-    p = fma(p, g, 2.7557319223985892511e-06);       // 1/9!
-    p = fma(p, g, 2.4801587301587301566e-05);       // 1/8!
-    p = fma(p, g, 1.9841269841269841253e-04);       // 1/7!
-    p = fma(p, g, 1.3888888888888889419e-03);       // 1/6!
-    p = fma(p, g, 8.3333333333333332177e-03);       // 1/5!
-    p = fma(p, g, 4.1666666666666664354e-02);       // 1/4!
-    p = fma(p, g, 1.6666666666666665741e-01);       // 1/3!
-    p = fma(p, g, 0.5);
-    p = fma(p, g, 1.0);
-    p = fma(p, g, 1.0);
-    const double kk = k < -1100.0 ? -1100.0 : (k > 1100.0 ? 1100.0 : k);
-    return ldexp(p, (int)kk);
-}
-
 // 10^(v/10) in float32: t = v log2(10)/10 = k + f with k = rint(t) and f formed by two fmas (the second one
 // carries the low part of the constant, so f is exact to ~1e-9), 2^f by v_exp_f32 (1 ulp), scaled by v_ldexp_f32.
 // v = -inf gives 0; NaN stays NaN.
