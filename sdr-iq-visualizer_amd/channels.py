@@ -53,6 +53,46 @@ class ChannelBank:
             raise ValueError(f"expected {len(self.rings)} channel inputs, got {len(frames_per_channel)}")
         self._per_channel(lambda c: self.rings[c].append_iq(frames_per_channel[c], hop=hop))
 
+    # -- IQ already on each channel's device: a continuous bank with nothing waited for that does not have to be --
+    def append_iq_device(self, d_iq_per_channel: Sequence[int], n_frames: int, frame_stride: Optional[int] = None, *,
+                         wait: bool = True) -> None:
+        """``d_iq_per_channel[c]``: device pointer (on ``devices[c]``) to ``n_frames`` frames of complex64 IQ for channel
+        c.  ``wait=False`` only enqueues the transforms on each ring's stream (``WaterfallBuffer.append_iq_device``)."""
+        if len(d_iq_per_channel) != len(self.rings):
+            raise ValueError(f"expected {len(self.rings)} device pointers, got {len(d_iq_per_channel)}")
+        if wait:
+            self._per_channel(lambda c: self.rings[c].append_iq_device(d_iq_per_channel[c], n_frames, frame_stride))
+        else:                       # enqueue-only calls return in microseconds: no threads needed
+            for c, ring in enumerate(self.rings):
+                ring.append_iq_device(d_iq_per_channel[c], n_frames, frame_stride, wait=False)
+
+    def gather_begin(self, max_rows: int, *, decimate: int = 1, mode: str = "max", out: Optional[np.ndarray] = None) -> np.ndarray:
+        """First half of a decimated gather of the newest ``max_rows`` rows of every channel into ONE host array
+        ``(channels, max_rows, nfft // decimate)`` (``out``: ideally ``pinned_empty``): every channel's reduction and
+        copy are enqueued, nothing is waited for.  Every channel must hold at least ``max_rows`` rows."""
+        rows, bins = int(max_rows), self.nfft // decimate
+        if min(len(r) for r in self.rings) < rows:
+            raise ValueError(f"every channel needs at least {rows} rows")
+        if out is None:
+            out = np.empty((len(self.rings), rows, bins), dtype=np.float32)
+        elif out.shape != (len(self.rings), rows, bins) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float32 array of shape {(len(self.rings), rows, bins)}")
+        for c, ring in enumerate(self.rings):
+            ring.gather_begin(max_rows=rows, decimate=decimate, mode=mode, out=out[c])
+        self._gather = out
+        return out
+
+    def gather_end(self) -> Optional[np.ndarray]:
+        """Second half: wait for every channel's copy; returns the array ``gather_begin`` filled."""
+        for ring in self.rings:
+            ring.gather_end()
+        g, self._gather = getattr(self, "_gather", None), None
+        return g
+
+    def sync(self) -> None:
+        for ring in self.rings:
+            ring.sync()
+
     def gather(self, max_rows: Optional[int] = None, *, decimate: int = 1, mode: str = "max") -> np.ndarray:
         """Host gather: float32 ``(channels, rows, nfft // decimate)``; channels with fewer rows are
         NaN-padded at the top (oldest side)."""

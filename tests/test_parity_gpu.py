@@ -998,6 +998,29 @@ def test_channel_bank_config5_shape(pkg):
     bank.append_iq([chans[0][:1]] + chans[1:])                   # ragged: channel 0 gets 1 row, the others 3
     g2 = bank.gather()
     assert g2.shape == (nch, 4, n) and not np.isnan(g2).any()    # every ring is full (maxlen 4)
+    # the continuous form: IQ resident on each channel's device, appends only enqueued, two-phase gather into ONE pinned array
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi
+    lib = _ffi.lib()
+    ptrs = []
+    for c, d in enumerate(devs):
+        p = ctypes.c_void_p()
+        _ffi.check(lib.sdrk_dev_alloc(d, chans[c].nbytes, ctypes.byref(p)))
+        _ffi.check(lib.sdrk_memcpy_h2d(d, p, chans[c].ctypes.data_as(ctypes.c_void_p), chans[c].nbytes))
+        ptrs.append(p)
+    try:
+        out = pkg.pinned_empty((nch, 2, 4096), np.float32)
+        bank.append_iq_device([p.value + n * 8 for p in ptrs], 2, wait=False)      # frames 1 and 2 of every channel
+        assert bank.gather_begin(2, decimate=256, out=out) is out
+        g3 = bank.gather_end()
+        for c in range(nch):
+            want = cpu_ref.spectrum_db(chans[c][1:], window=np.hanning(n))
+            assert_db_parity(bank.rings[c].as_array(max_rows=2), want, what=f"channel {c} device append")
+            assert np.array_equal(g3[c], bank.rings[c].as_array(max_rows=2).reshape(2, 4096, 256).max(-1))
+        bank.sync()
+    finally:
+        for d, p in zip(devs, ptrs):
+            lib.sdrk_dev_free(d, p)
     bank.close()
 
 
