@@ -824,6 +824,13 @@ def test_waterfall_async_append_and_two_phase_gather(pkg):
         lib.sdrk_dev_free(0, d_in)
 
 
+def test_host_boundary_randomised(pkg):
+    """tools/stress_host.py with a fixed seed: 48 random calls through the numpy boundary (lengths 2 ... 2^17 and odd ones,
+    gaps and overlaps between frames, pageable and pinned arrays on either side, every window / shift / eps setting)."""
+    from tools import stress_host
+    assert stress_host.run(48, 11) == 48
+
+
 def test_waterfall_decimated_readout(pkg):
     """f4 (build-side extension): device max-hold / mean decimation of ring rows before D2H."""
     rng = np.random.default_rng(31)
