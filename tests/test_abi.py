@@ -59,6 +59,15 @@ def test_product_path_fails_loudly_without_a_device():
         pkg.WaterfallBuffer(4096)
     with pytest.raises(pkg.SdrkError):
         pkg.process_frame(np.zeros(4096, dtype=np.complex64), 1e6, 2.4e9)
+    with pytest.raises(pkg.SdrkError):
+        pkg.pinned_empty((4, 4096), np.float32)
+    with pytest.raises(pkg.SdrkError):
+        with pkg.registered(np.zeros(4096, dtype=np.complex64)):
+            pass
+    from sdr_iq_visualizer_amd import features
+    with pytest.raises(pkg.SdrkError):
+        features.row_features(np.zeros(4096, dtype=np.float32))
+    assert pkg.is_pinned(np.zeros(16, dtype=np.float32)) is False      # answers without a device: nothing is registered
 
 
 def _build_c_smoke(tmp_path):
