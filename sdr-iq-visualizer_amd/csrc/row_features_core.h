@@ -215,6 +215,119 @@ __device__ __forceinline__ void rf_opaque(float (&v)[16]) {
 }
 
 // Everything scans A / B and the select produced, for the common tail.
+// k-th smallest of a row that is read where it lies (LDS or L2 / HBM), and the next one up: q0, q1.
+// A histogram of the VALUE, as rf_small's, refined level by level: level 0 has 2048 bins of 1/16 dB around the
+// row's mean; while the bin that holds rank k has more than RF_CAND members, the next level splits THAT bin into
+// 2048 (t' = (t - b) * 2048: exact in float32, monotone), up to three levels (1.5e-8 dB: below float32 spacing).
+// The members of the last bin are then ranked exactly, as in rf_small.  One pass over the row per level, one to
+// collect, one for q1 (the smallest value above q0, or q0 again when it is tied with rank k+1).  Unlike the byte
+// histogram of rf_select_pair the lanes of a wave land in different bins (dB rows spread over many 1/16 dB bins but
+// share their high key bytes), so the LDS atomics do not serialise.  Returns false (nothing decided) when the row
+// has non-finite values (the caller passes that in), when rank k lies outside the level-0 window, or when more
+// than RF_CAND values are tied: the caller then runs rf_select_pair.
+template <class RowPtr>
+__device__ __forceinline__ bool rf_select_hist(RowPtr x, int n, unsigned rank, float center, bool finite,
+                                               RowFeatShared& sh, float& q0, float& q1, int tid) {
+    if (!finite) return false;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float off0 = -RF_BINS_PER_DB * (center - (float)(RF_BINS / 2) / RF_BINS_PER_DB);
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+    unsigned want = rank;
+    int level = 0;
+    // coordinate of v at level `upto` and whether v lies inside the bins chosen at the levels above it
+    auto place = [&](float v, int upto, float& t) -> bool {
+        t = fminf(fmaxf(fmaf(v, RF_BINS_PER_DB, off0), 0.0f), (float)(RF_BINS - 1));
+        bool in = true;
+        if (upto >= 1) { in = t >= p0 && t < p0 + 1.0f; t = (t - p0) * (float)RF_BINS; }
+        if (upto >= 2) { in = in && t >= p1 && t < p1 + 1.0f; t = (t - p1) * (float)RF_BINS; }
+        if (upto >= 3) { in = in && t >= p2 && t < p2 + 1.0f; }
+        return in;
+    };
+    for (;; ++level) {
+        typedef unsigned rf_v4u __attribute__((ext_vector_type(4)));
+        rf_v4u* b4 = reinterpret_cast<rf_v4u*>(sh.bins);
+        __syncthreads();
+        b4[2 * tid] = rf_v4u{0u, 0u, 0u, 0u};
+        b4[2 * tid + 1] = rf_v4u{0u, 0u, 0u, 0u};
+        if (tid == 0) sh.sel[3] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += RF_THREADS) {
+            float t;
+            if (place(x[i], level, t)) atomicAdd(&sh.bins[(int)t], 1u);
+        }
+        __syncthreads();
+        unsigned c[8];
+        {
+            const rf_v4u a = b4[2 * tid], b = b4[2 * tid + 1];
+            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        }
+        const unsigned tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+        unsigned incl = rf_wave_scan_add(tot);
+        if (lane == 63) sh.wtot[wave] = incl;
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) incl += sh.wtot[w];
+        const unsigned excl = incl - tot;
+        if (excl <= want && want < incl) {            // exactly one thread: its bins hold the rank
+            unsigned cum = excl;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (want >= cum && want < cum + c[k]) { sh.sel[0] = 8 * tid + k; sh.sel[1] = (int)c[k]; sh.sel[2] = (int)cum; }
+                cum += c[k];
+            }
+        }
+        __syncthreads();
+        const int b = sh.sel[0], members = sh.sel[1];
+        if (level == 0 && (b < 1 || b > RF_BINS - 2)) return false;     // clamped: the edge bins are open-ended
+        want -= (unsigned)sh.sel[2];
+        if (level == 0) p0 = (float)b; else if (level == 1) p1 = (float)b; else p2 = (float)b;
+        if (members <= RF_CAND) break;
+        if (level == 2) return false;                                    // > RF_CAND values tied to float32 spacing
+    }
+    // the members of the last bin, ranked exactly (ties by list position)
+    for (int i = tid; i < n; i += RF_THREADS) {
+        const float v = x[i];
+        float t;
+        if (place(v, level + 1, t)) {                                     // inside bins p0 .. p<level>
+            const int pos = atomicAdd(&sh.sel[3], 1);
+            if (pos < RF_CAND) sh.cand[pos] = v;
+        }
+    }
+    __syncthreads();
+    const int K = sh.sel[3];
+    if (wave == 0) {
+        const float mine = lane < K ? sh.cand[lane] : INFINITY;
+        unsigned rk = 0;
+        for (int j = 0; j < K; ++j) {
+            const float cj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), j));
+            rk += (cj < mine || (cj == mine && j < lane)) ? 1u : 0u;
+        }
+        if (lane < K && rk == want) sh.f[0] = mine;
+    }
+    __syncthreads();
+    q0 = sh.f[0];
+    // q1: values <= q0 number more than rank + 1 -> the next order statistic is q0 again; else the smallest above
+    unsigned le = 0;
+    float next = INFINITY;
+    for (int i = tid; i < n; i += RF_THREADS) {
+        const float v = x[i];
+        if (v <= q0) ++le;
+        else next = fminf(next, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        le += __shfl_down(le, o, 64);
+        next = fminf(next, __shfl_down(next, o, 64));
+    }
+    __syncthreads();
+    if (lane == 0) { sh.wtot[wave] = le; sh.cand[wave] = next; }
+    __syncthreads();
+    le = sh.wtot[0] + sh.wtot[1] + sh.wtot[2] + sh.wtot[3];
+    next = fminf(fminf(sh.cand[0], sh.cand[1]), fminf(sh.cand[2], sh.cand[3]));
+    q1 = (le > rank + 1 || rank + 1 >= (unsigned)n) ? q0 : next;
+    __syncthreads();
+    return true;
+}
+
 struct RowFeatValues {
     float mx, q0, q1;
     int amx;
@@ -335,7 +448,8 @@ __device__ __forceinline__ void rf_large(RowPtr x, int n, const RowFeatParams& p
 
     // order statistics for numpy.percentile's linear interpolation
     const int r0 = prm.rank < 0 ? 0 : (prm.rank > n - 1 ? n - 1 : prm.rank);
-    rf_select_pair(x, n, (unsigned)r0, sh, r.q0, r.q1, tid);
+    if (!rf_select_hist(x, n, (unsigned)r0, (float)mean, mean - mean == 0.0, sh, r.q0, r.q1, tid))
+        rf_select_pair(x, n, (unsigned)r0, sh, r.q0, r.q1, tid);
     rf_finish(r, n, prm, sh, o_stats, o_thr, tid);
     if (o_idx && o_cnt) rf_peaks(x, n, prm, sh, o_idx, o_cnt, tid);
 }
