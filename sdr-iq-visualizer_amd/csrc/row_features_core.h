@@ -91,6 +91,12 @@ __device__ __forceinline__ float rf_pow10_tenth_f32(float v) {
     return v == -INFINITY ? 0.0f : p;
 }
 
+// sum of the per-wave totals of the waves before `wave` (four waves; branch-free: written as a loop over w < wave
+// the compiler does not know the trip count is <= 3 and emits an unrolled-by-8 loop with spills around it)
+__device__ __forceinline__ unsigned rf_waves_before(const unsigned* t, int wave) {
+    return (wave > 0 ? t[0] : 0u) + (wave > 1 ? t[1] : 0u) + (wave > 2 ? t[2] : 0u);
+}
+
 // k-th smallest (0-based) of x[0..n) and the (k+1)-th: q0, q1 (q1 == q0 when k == n-1).
 // Exact radix select, 8 bits per pass.  Two things keep a pass short: (1) dB rows share their sign and high
 // exponent bits, so in the top-byte pass nearly every key lands in the same 1-3 bins — that pass counts equal
@@ -137,7 +143,7 @@ __device__ __forceinline__ void rf_select_pair(RowPtr x, int n, unsigned rank, R
         if (lane == 63) sh.state[wave] = incl;
         __syncthreads();
         unsigned before = 0;
-        for (int w = 0; w < wave; ++w) before += sh.state[w];
+        before = rf_waves_before(sh.state, wave);
         incl += before;
         __syncthreads();
         if (want >= incl - h && want < incl) {                   // exactly one thread: its bin holds the rank
@@ -265,7 +271,7 @@ __device__ __forceinline__ bool rf_select_hist(RowPtr x, int n, unsigned rank, f
         unsigned incl = rf_wave_scan_add(tot);
         if (lane == 63) sh.wtot[wave] = incl;
         __syncthreads();
-        for (int w = 0; w < wave; ++w) incl += sh.wtot[w];
+        incl += rf_waves_before(sh.wtot, wave);
         const unsigned excl = incl - tot;
         if (excl <= want && want < incl) {            // exactly one thread: its bins hold the rank
             unsigned cum = excl;
@@ -615,7 +621,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     unsigned incl = rf_wave_scan_add(tot);
     if (lane == 63) sh.wtot[wave] = incl;
     __syncthreads();
-    for (int w = 0; w < wave; ++w) incl += sh.wtot[w];
+    incl += rf_waves_before(sh.wtot, wave);
     const unsigned excl = incl - tot;
     if (excl <= r0 && r0 < incl) {            // exactly one thread: its bins hold rank r0
         unsigned cum = excl;
