@@ -91,6 +91,16 @@ __device__ __forceinline__ float rf_pow10_tenth_f32(float v) {
     return v == -INFINITY ? 0.0f : p;
 }
 
+// the same for v > -149 dB (the clip-free scan of rf_small): no lower exponent clamp, no -inf case
+__device__ __forceinline__ float rf_pow10_tenth_f32_inrange(float v) {
+    const float C_HI = 0.33219280948873623479f;
+    const float C_LO = (float)(0.33219280948873623479 - (double)C_HI);
+    const float k = rintf(v * C_HI);
+    float f = fmaf(v, C_HI, -k);
+    f = fmaf(v, C_LO, f);
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)fminf(k, 300.0f));
+}
+
 // sum of the per-wave totals of the waves before `wave` (four waves; branch-free: written as a loop over w < wave
 // the compiler does not know the trip count is <= 3 and emits an unrolled-by-8 loop with spills around it)
 __device__ __forceinline__ unsigned rf_waves_before(const unsigned* t, int wave) {
@@ -501,7 +511,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
                 const float v = xv[j];
                 if (v > mx) { mx = v; amx = i; }
                 su += (double)v;
-                sp += (double)rf_pow10_tenth_f32(v);
+                sp += (double)rf_pow10_tenth_f32_inrange(v);
             }
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four elements in flight at a time (register pressure)
         }
@@ -694,13 +704,30 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
 // scalar lookup per word) and learns every word's true entry state;  (3) lane w replays word w from that state,
 // which yields its accepted bins, and the indices leave in order by a prefix sum of the counts.  Exact by
 // construction (the same recurrence, evaluated speculatively); ~4x less time on the critical wave.
-__device__ __forceinline__ void rf_accept_word(unsigned long long m, unsigned long long dspan, unsigned long long& acc) {
-    acc = 0;
-    while (__any(m != 0)) {          // wave-uniform trip count: the lane with the most accepted peaks in its word
-        if (m != 0) {
-            const int bit = __builtin_ctzll(m);
-            acc |= 1ull << bit;
-            m &= ~(dspan << bit);
+// One 64-bin word: candidates (mlo, mhi) with the entry suppression already applied; accepts greedily, low half then
+// high half, all in 32-bit operations (d <= 16 < 32: a span reaches at most into the next half).  `last` = the last
+// accepted bin of the word or -1; (alo, ahi) = the accepted bins when ACC.  Trip counts are wave-uniform: the lane
+// with the most accepted peaks in a half.
+template <bool ACC>
+__device__ __forceinline__ void rf_accept_word(unsigned mlo, unsigned mhi, int d, unsigned& alo, unsigned& ahi, int& last) {
+    const unsigned dspan = (1u << d) - 1u;
+    alo = 0; ahi = 0; last = -1;
+    while (__any(mlo != 0)) {
+        if (mlo != 0) {
+            const int bit = __builtin_ctz(mlo);
+            if (ACC) alo |= 1u << bit;
+            last = bit;
+            mlo &= ~(dspan << bit);                       // bins past 31 fall off: handled below
+        }
+    }
+    const int carry = last + d - 32;                       // leading bins of the high half still suppressed (< 16)
+    mhi = carry > 0 ? mhi & (~0u << carry) : mhi;
+    while (__any(mhi != 0)) {
+        if (mhi != 0) {
+            const int bit = __builtin_ctz(mhi);
+            if (ACC) ahi |= 1u << bit;
+            last = 32 + bit;
+            mhi &= ~(dspan << bit);
         }
     }
 }
@@ -709,9 +736,10 @@ template <class RowPtr>
 __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, int n, const RowFeatParams& prm,
                                                RowFeatShared& sh, int* __restrict__ o_idx, int* __restrict__ o_cnt, int tid) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const double thr = sh.thr;
     const int d = prm.min_distance;
-    const unsigned long long dspan = (1ull << d) - 1ull;
+    // v > thr (float64 threshold) <=> v > the largest float32 <= thr: one float compare per bin
+    float thr_f = (float)sh.thr;
+    if ((double)thr_f > sh.thr) thr_f = nextafterf(thr_f, -INFINITY);
     // candidates: strict local maxima above the threshold; word 4 j + wave holds bins 256 j + 64 wave + lane
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -719,7 +747,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
         bool cand = false;
         if (i >= 1 && i < n - 1) {
             const float v = xv[j];
-            cand = (double)v > thr && v > x[i - 1] && v > x[i + 1];
+            cand = v > thr_f && v > x[i - 1] && v > x[i + 1];
         }
         const unsigned long long b = __ballot(cand);
         if (lane == 0) sh.flags[4 * j + wave] = b;
@@ -730,11 +758,12 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
 #pragma unroll 1
     for (int round = 0; round < 4; ++round) {
         const int w = 16 * wave + 4 * round + grp;
-        unsigned long long m = sh.flags[w] & (~0ull << st);
-        unsigned long long acc;
-        rf_accept_word(m, dspan, acc);
+        const unsigned long long m = sh.flags[w];
+        unsigned alo, ahi;
+        int last;
+        rf_accept_word<false>((unsigned)m & (~0u << st), (unsigned)(m >> 32), d, alo, ahi, last);
         // exit state: bins of the next word still inside the last accepted peak's span
-        int ex = acc ? 63 - __builtin_clzll(acc) + d - 64 : 0;
+        int ex = last + d - 64;
         ex = ex < 0 ? 0 : ex;
         unsigned lo = st < 8 ? (unsigned)ex << (4 * st) : 0u, hi = st >= 8 ? (unsigned)ex << (4 * (st - 8)) : 0u;
         // OR over the 16 entry states of the word (one DPP row): lane 15 of the row ends up with the table
@@ -760,16 +789,26 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
             s = (unsigned)(T >> (4 * s)) & 15u;
         }
         // (3) replay word `lane` from its entry state; indices out in order
-        unsigned long long acc;
-        rf_accept_word(sh.flags[lane] & (~0ull << entry), dspan, acc);
-        const unsigned pc = (unsigned)__popcll(acc);
+        const unsigned long long m = sh.flags[lane];
+        unsigned alo, ahi;
+        int last;
+        rf_accept_word<true>((unsigned)m & (~0u << entry), (unsigned)(m >> 32), d, alo, ahi, last);
+        const unsigned pc = (unsigned)(__popc(alo) + __popc(ahi));
         const unsigned incl = rf_wave_scan_add(pc);
         unsigned pos = incl - pc;
-        while (__any(acc != 0)) {
-            if (acc != 0) {
-                const int bit = __builtin_ctzll(acc);
-                acc &= acc - 1;
+        while (__any(alo != 0)) {
+            if (alo != 0) {
+                const int bit = __builtin_ctz(alo);
+                alo &= alo - 1;
                 if ((int)pos < prm.max_peaks) o_idx[pos] = 64 * lane + bit;
+                ++pos;
+            }
+        }
+        while (__any(ahi != 0)) {
+            if (ahi != 0) {
+                const int bit = __builtin_ctz(ahi);
+                ahi &= ahi - 1;
+                if ((int)pos < prm.max_peaks) o_idx[pos] = 64 * lane + 32 + bit;
                 ++pos;
             }
         }
