@@ -209,15 +209,12 @@ __device__ __forceinline__ double rf_wave_scan_add(double v) {
     return v;
 }
 // (value, index) with "larger value, then smaller index" wins: lane 63 ends up with the wave's max and its first index
-__device__ __forceinline__ void rf_wave_scan_argmax(float& mx, int& amx) {
-#define RF_STEP(CTRL, ROWS)                                                                                   \
-    {                                                                                                         \
-        const float om = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000, __builtin_bit_cast(int, mx), CTRL, ROWS, 0xf, false)); \
-        const int oi = __builtin_amdgcn_update_dpp(0x7fffffff, amx, CTRL, ROWS, 0xf, false);                  \
-        if (om > mx || (om == mx && oi < amx)) { mx = om; amx = oi; }                                         \
-    }
+__device__ __forceinline__ float rf_wave_scan_max(float mx) {
+#define RF_STEP(CTRL, ROWS) \
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000, __builtin_bit_cast(int, mx), CTRL, ROWS, 0xf, false)));
     RF_DPP_STEPS(RF_STEP)
 #undef RF_STEP
+    return mx;
 }
 __device__ __forceinline__ double rf_lane63(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
@@ -509,7 +506,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
             const int i = tid + RF_THREADS * j;
             if (i < n) {
                 const float v = xv[j];
-                if (v > mx) { mx = v; amx = i; }
+                mx = fmaxf(mx, v);
                 su += (double)v;
                 sp += (double)rf_pow10_tenth_f32_inrange(v);
             }
@@ -521,7 +518,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
             const int i = tid + RF_THREADS * j;
             if (i < n) {
                 const float v = xv[j];
-                if (v > mx) { mx = v; amx = i; }
+                mx = fmaxf(mx, v);
                 const double dv = (double)v;
                 const float p = rf_pow10_tenth_f32(v);
                 const bool clip = p < 1e-15f;                 // np.clip(p, 1e-15, None) (NaN stays NaN)
@@ -534,7 +531,17 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
         }
     }
     double sx = su + sc;
-    rf_wave_scan_argmax(mx, amx);
+    // the wave's maximum (NaNs skipped, as a running `v > mx` does), then its first bin: bin i = 256 j + 64 wave +
+    // lane, so the first set bit of the first non-empty ballot over j.  (A wave whose maximum stayed -inf has no
+    // bin ABOVE -inf: no argmax, as before.)
+    mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rf_wave_scan_max(mx)), 63));
+    if (mx > -INFINITY) {
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            const unsigned long long b = __ballot(tid + RF_THREADS * j < n && xv[j] == mx);
+            if (b) amx = RF_THREADS * j + 64 * wave + __builtin_ctzll(b);
+        }
+    }
     sx = rf_wave_scan_add(sx);
     sp = rf_wave_scan_add(sp);
     if (careful) {
@@ -779,15 +786,20 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
         // (2) the walk: entry state of every word
         const unsigned long long mine = sh.tbl[lane];
         const int t_lo = (int)(unsigned)mine, t_hi = (int)(unsigned)(mine >> 32);
-        int entry = 0;
+        // (scalar: the entry states collect as nibbles of eight scalar words; each lane then picks its own)
+        unsigned ent[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         unsigned s = 0;                                    // nothing accepted before bin 0 (pk[0] = -d)
-#pragma unroll 8
+#pragma unroll
         for (int w = 0; w < 64; ++w) {
-            entry = lane == w ? (int)s : entry;
+            ent[w >> 3] |= s << (4 * (w & 7));
             const unsigned long long T = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(t_hi, w) << 32) |
                                          (unsigned)__builtin_amdgcn_readlane(t_lo, w);
             s = (unsigned)(T >> (4 * s)) & 15u;
         }
+        unsigned mine_ent = ent[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) mine_ent = (lane >> 3) == k ? ent[k] : mine_ent;
+        const int entry = (int)((mine_ent >> (4 * (lane & 7))) & 15u);
         // (3) replay word `lane` from its entry state; indices out in order
         const unsigned long long m = sh.flags[lane];
         unsigned alo, ahi;
