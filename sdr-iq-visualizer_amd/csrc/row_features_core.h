@@ -341,6 +341,27 @@ __device__ __forceinline__ bool rf_select_hist(RowPtr x, int n, unsigned rank, f
     return true;
 }
 
+// One IEEE operation each, never part of an fma: numpy rounds after every operation, and HIP's __fmul_rn / __fadd_rn
+// are plain `x * y` / `x + y` that the compiler contracts after inlining (found by tools/stress_features.py: a
+// threshold one float32 ulp off in ~1 row of 60 once the surrounding code changed).  The pragma takes the `contract`
+// flag off the operation where it is written, so it survives inlining.
+__device__ __forceinline__ float rf_mul_f32(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float rf_add_f32(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float rf_sub_f32(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ double rf_mul_f64(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 struct RowFeatValues {
     float mx, q0, q1;
     int amx;
@@ -359,11 +380,11 @@ __device__ __forceinline__ void rf_finish(const RowFeatValues& r, int n, const R
         // operation rounded to float32 (no contraction); then classifier.py:46,55 with NEP-50 promotion:
         // snr = float32(max - nf) widened; second = (max - float32(0.9*snr)) + 5 in float32; first = nf + 5 in
         // float64; python max(first, second) compares second > float32(first).
-        const float diff = __fsub_rn(r.q1, r.q0);
-        float nf = __fadd_rn(r.q0, __fmul_rn(diff, prm.gamma));
-        if (prm.gamma >= 0.5f) nf = __fsub_rn(r.q1, __fmul_rn(diff, __fsub_rn(1.0f, prm.gamma)));
-        const double snr = (double)__fsub_rn(r.mx, nf);
-        const float second = __fadd_rn(__fsub_rn(r.mx, (float)(0.9 * snr)), 5.0f);
+        const float diff = rf_sub_f32(r.q1, r.q0);
+        float nf = rf_add_f32(r.q0, rf_mul_f32(diff, prm.gamma));
+        if (prm.gamma >= 0.5f) nf = rf_sub_f32(r.q1, rf_mul_f32(diff, rf_sub_f32(1.0f, prm.gamma)));
+        const double snr = (double)rf_sub_f32(r.mx, nf);
+        const float second = rf_add_f32(rf_sub_f32(r.mx, (float)rf_mul_f64(0.9, snr)), 5.0f);
         const double first = (double)nf + 5.0;
         sh.thr = second > (float)first ? (double)second : first;
         if (o_thr) *o_thr = sh.thr;

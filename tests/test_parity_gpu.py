@@ -735,6 +735,37 @@ def test_row_features_special_rows(pkg):
     assert got["adaptive_threshold_db"] == ref["adaptive_threshold_db"]
 
 
+def test_adaptive_threshold_is_not_contracted(pkg):
+    """numpy rounds the percentile's a + (b - a) * gamma after every operation; the device once formed it as ONE fma
+    (hipcc contracts HIP's __fmul_rn / __fadd_rn after inlining) and the threshold came out a float32 ulp high.  The
+    order statistics, gamma and maximum of the row tools/stress_features.py caught (seed 7, case 60), and 200 random
+    triples: for these the fused and the rounded form differ, so a contracted build fails here."""
+    from sdr_iq_visualizer_amd import features
+    n = 2048
+    rank, gamma = features.percentile_rank(n, 20.0), features.percentile_gamma(n, 20.0)
+    freqs = cpu_ref.freq_axis(n, 2e6, 1e9)
+    rng = np.random.default_rng(60)
+    triples = [(np.float32(-90.5903091430664), np.float32(-87.97126007080078), np.float32(-12.301048278808594))]
+    while len(triples) < 201:
+        q0 = np.float32(rng.uniform(-120, -60))
+        q1 = np.float32(q0 + rng.uniform(0.01, 5))
+        diff = np.float32(q1 - q0)
+        if np.float32(q0 + np.float32(diff * gamma)) != np.float32(float(q0) + float(diff) * float(gamma)):
+            triples.append((q0, q1, np.float32(rng.uniform(-30, 0))))
+    rows = np.empty((len(triples), n), dtype=np.float32)
+    for r, (q0, q1, mx) in enumerate(triples):
+        rows[r, :rank] = q0 - np.float32(10)
+        rows[r, rank], rows[r, rank + 1] = q0, q1
+        rows[r, rank + 2:] = q1 + np.float32(20)
+        rows[r, -1] = mx
+        rng.shuffle(rows[r])
+    got = features.row_features(rows, freqs)
+    for r in range(len(triples)):
+        ref = cpu_ref.row_features(freqs, rows[r])
+        assert got[r]["noise_floor_db"] == ref["noise_floor_db"], r
+        assert got[r]["adaptive_threshold_db"] == ref["adaptive_threshold_db"], (r, triples[r])
+
+
 def test_peak_scan_every_spacing(pkg):
     """classifier.py:200-212 for spacings on both sides of the speculative-parallel scan's limit (min_distance <= 16 runs
     it, larger ones the scalar recurrence) and row lengths that leave the last 64-bin word partly empty: the accepted

@@ -21,7 +21,7 @@ def run(cases, seed):
 
 def one_case(c, rng, done):
     if True:
-        n = int(rng.choice([64, 100, 257, 1000, 2048, 4000, 4096, 4097, 8192, 30000, 40000]))
+        n = int(rng.choice([64, 100, 257, 1000, 2048, 4000, 4096, 4097, 8192, 30000, 40000, 70000, 131072]))
         kind = kinds[c % len(kinds)]
         x = (rng.standard_normal(n) * rng.uniform(1, 9) + rng.uniform(-120, 60)).astype(np.float32)
         if kind == "quantised":                       # heavy ties: more than 64 equal values around the percentile
