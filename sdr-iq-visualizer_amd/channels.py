@@ -30,6 +30,12 @@ class ChannelBank:
         for r in self.rings:
             r.close()
 
+    def __enter__(self) -> "ChannelBank":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
     def _per_channel(self, fn: Callable[[int], None]) -> None:
         errors: List[BaseException] = []
 

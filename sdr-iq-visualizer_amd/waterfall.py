@@ -53,6 +53,12 @@ class WaterfallBuffer:
             self._plan.close()
             self._plan = None
 
+    def __enter__(self) -> "WaterfallBuffer":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
     def __del__(self):  # pragma: no cover - best effort
         try:
             self.close()

@@ -862,6 +862,15 @@ def test_host_boundary_randomised(pkg):
     assert stress_host.run(48, 11) == 48
 
 
+def test_waterfall_randomised_against_deque(pkg):
+    """tools/stress_waterfall.py with a fixed seed: 16 random sequences of 30 operations on a WaterfallBuffer (rows from
+    the host, packed / overlapped / device-resident IQ, enqueued-only appends, clear, partial and decimated read-outs in one
+    and two phases) against collections.deque, the reference's container (callbacks.py:19,176,182)."""
+    from tools import stress_waterfall
+    done = stress_waterfall.run(16, 5, steps=30)
+    assert sum(done.values()) == 16 * 30
+
+
 def test_waterfall_decimated_readout(pkg):
     """f4 (build-side extension): device max-hold / mean decimation of ring rows before D2H."""
     rng = np.random.default_rng(31)
