@@ -546,6 +546,31 @@ def test_thread_per_device_sharding_every_visible_gpu(pkg):
     assert np.array_equal(split, whole)
 
 
+def test_sharding_randomised_equals_one_device(pkg):
+    """Frame-range sharding is a pure partition: for random frame lengths, frame counts (also fewer
+    frames than shards), hops and shard counts the gathered rows equal the one-device result bit for bit."""
+    devs = visible_devices(pkg)
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        n = int(rng.choice([64, 1000, 1024, 4096, 8192, 65536]))
+        shards = int(rng.integers(1, 8))
+        dev_list = [devs[i % len(devs)] for i in range(shards)]
+        window = None if rng.random() < 0.5 else "hann"
+        if rng.random() < 0.5:
+            frames = int(rng.integers(1, 3 * shards + 2))
+            x = rand_c64(rng, frames, n, scale=float(rng.uniform(0.1, 50)))
+            one = pkg.spectrum_db(x, window=window, devices=[devs[0]])
+            many = pkg.spectrum_db(x, window=window, devices=dev_list)
+        else:
+            hop = int(rng.integers(1, 2 * n))
+            rows = int(rng.integers(1, 3 * shards + 2))
+            x = rand_c64(rng, n + (rows - 1) * hop + int(rng.integers(0, hop)), scale=float(rng.uniform(0.1, 50)))
+            one = pkg.stft_db(x, n, hop, window=window)
+            many = pkg.stft_db(x, n, hop, window=window, devices=dev_list)
+            assert one.shape == (rows, n)
+        assert np.array_equal(one, many), (case, n, shards, window)
+
+
 @pytest.mark.parametrize("n,batch", [(8192, 9), (16384, 7), (1 << 20, 3)])
 def test_sharding_kernels_with_more_than_64k_lds_on_every_device(pkg, n, batch):
     """N = 8192 / 16384 (70 / 139 KiB of LDS) and N = 2^20 (col pass 139 KiB) need the dynamic-LDS
