@@ -734,6 +734,15 @@ def test_frame_features_rows_stay_on_device(pkg, n, window):
     _features_equal(one, got[0])
 
 
+def test_frame_features_randomised_kinds(pkg):
+    """tools/stress_fused.py with a fixed seed: 60 batches of IQ frames of eleven kinds (noise, silence, impulse, tones on
+    and off a bin, bursts, 12-bit integers, clipped, DC, two tones, magnitudes at the additive floor) through the fused
+    N = 4096 kernel and the transform + single-read pair, against the oracle on the rows the device returned."""
+    from tools import stress_fused
+    done = stress_fused.run(60, 9)
+    assert all(v > 0 for v in done.values()), done
+
+
 def test_row_features_special_rows(pkg):
     """Edge cases of the reductions: the all-zero frame's -240 dB row (every value equal: sigma 0, flatness 1,
     no peaks), rows with -inf (eps = 0) and an all-NaN row (empty band sentinels -> 0 Hz, as the reference)."""
