@@ -1148,6 +1148,20 @@ def test_edge_cases_errors_and_special_values(pkg):
     assert wf.as_array().shape == (1, 1000)
 
 
+def test_c_abi_refuses_invalid_arguments(pkg):
+    """tools/abi_invalid_probe.py: ~75 calls across every C entry point with arguments it must refuse (NULL pointers,
+    devices that do not exist, zero lengths, a plan of another frame length, unknown flags / modes).  Each returns a
+    negative status with a message; nothing crashes, nothing is left allocated, and the handles still work."""
+    from sdr_iq_visualizer_amd import _ffi
+    from tools import abi_invalid_probe
+    seen = 0
+    for what, status in abi_invalid_probe.cases():
+        assert status < 0, f"accepted: {what}"
+        assert _ffi.lib().sdrk_last_error(), what
+        seen += 1
+    assert seen >= 70
+
+
 def test_config3_full_size_sampled_rows(pkg):
     """BASELINE.json config 3 at full size: 10 s @ 61.44 Msps = 614 400 000 samples on the device,
     N = 65536, hop = 32768, Hann -> 18 749 rows (9.8 GB through the kernels); rows sampled across the run
