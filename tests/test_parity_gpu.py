@@ -1148,6 +1148,103 @@ def test_edge_cases_errors_and_special_values(pkg):
     assert wf.as_array().shape == (1, 1000)
 
 
+def test_threads_share_the_library(pkg):
+    """SURVEY.md §8b threading: the reference transforms on one producer thread (streamer.py:58) while Flask request
+    threads append to and read the waterfall (callbacks.py:176,182).  Here: eight threads through the module-level
+    (cached, locked) plans and through plans of their own at the same time, four writers and a reader on one
+    WaterfallBuffer, and sdrk_last_error() staying per-thread."""
+    import threading
+    from sdr_iq_visualizer_amd import _ffi
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    rng = np.random.default_rng(123)
+    sizes = [4096, 4096, 1024, 4096, 65536, 1000, 4096, 256]
+    inputs = [rand_c64(rng, 3, n, scale=10.0) for n in sizes]
+    want = [pkg.spectrum_db(x, window="hann") for x in inputs]          # one thread, for comparison
+    errors, results = [], [None] * len(sizes)
+
+    def guarded(fn):
+        def run(*a):
+            try:
+                fn(*a)
+            except BaseException as e:                                   # noqa: BLE001 - reported on the main thread
+                errors.append(e)
+        return run
+
+    @guarded
+    def shared_plans(t):
+        for _ in range(12):
+            got = pkg.spectrum_db(inputs[t], window="hann")
+            assert np.array_equal(got, want[t]), f"thread {t}: shared plan result changed"
+        results[t] = True
+
+    @guarded
+    def own_plan(t):
+        with SpectrumPlan(sizes[t], window="hann") as plan:
+            for _ in range(12):
+                assert np.array_equal(plan.spectrum_db(inputs[t]), want[t]), f"thread {t}: own plan result changed"
+
+    threads = [threading.Thread(target=shared_plans, args=(t,)) for t in range(len(sizes))]
+    threads += [threading.Thread(target=own_plan, args=(t,)) for t in range(len(sizes))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[0]
+    assert all(results)
+
+    # four writers (rows tagged writer * 1000 + sequence number), one reader, ring of 50
+    wf = pkg.WaterfallBuffer(512, maxlen=50)
+    per_writer, stop = 120, threading.Event()
+
+    @guarded
+    def writer(wid):
+        for k in range(per_writer):
+            wf.append(np.full(512, wid * 1000 + k, dtype=np.float32))
+
+    @guarded
+    def reader():
+        while not stop.is_set():
+            a = wf.as_array()
+            assert a.shape[0] <= 50 and a.shape[1] == 512
+            assert np.all(a == a[:, :1]), "a row mixes two appends"
+            for wid in range(4):                                         # each writer's rows stay in its own order
+                seq = a[:, 0][(a[:, 0] // 1000).astype(int) == wid]
+                assert np.all(np.diff(seq) > 0), f"writer {wid}: rows out of order"
+
+    ws = [threading.Thread(target=writer, args=(w,)) for w in range(4)]
+    rd = threading.Thread(target=reader)
+    rd.start()
+    for th in ws:
+        th.start()
+    for th in ws:
+        th.join()
+    stop.set()
+    rd.join()
+    assert not errors, errors[0]
+    final = wf.as_array()
+    assert len(wf) == 50 and final.shape == (50, 512)
+    for wid in range(4):
+        seq = final[:, 0][(final[:, 0] // 1000).astype(int) == wid]
+        assert np.all(np.diff(seq) > 0)
+    wf.close()
+
+    # the error string belongs to the thread that caused it
+    lib = _ffi.lib()
+    seen = {}
+
+    @guarded
+    def provoke(name, call):
+        for _ in range(200):
+            assert call() < 0
+            seen[name] = lib.sdrk_last_error().decode()
+            assert name in seen[name], (name, seen[name])
+
+    a = threading.Thread(target=provoke, args=("waterfall", lambda: lib.sdrk_waterfall_rows(None)))
+    b = threading.Thread(target=provoke, args=("plan", lambda: lib.sdrk_plan_nfft(None)))
+    a.start(); b.start(); a.join(); b.join()
+    assert not errors, errors[0]
+
+
 def test_c_abi_refuses_invalid_arguments(pkg):
     """tools/abi_invalid_probe.py: ~75 calls across every C entry point with arguments it must refuse (NULL pointers,
     devices that do not exist, zero lengths, a plan of another frame length, unknown flags / modes).  Each returns a
