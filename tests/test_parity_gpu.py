@@ -743,6 +743,53 @@ def test_frame_features_randomised_kinds(pkg):
     assert all(v > 0 for v in done.values()), done
 
 
+@pytest.mark.parametrize("n", [4096, 1024])
+def test_frame_features_device_strides(pkg, n):
+    """sdrk_frame_features_device on one resident IQ stream cut with overlapping (hop < N), packed and gapped
+    (hop > N) frames: rows, statistics, thresholds and peak lists equal those of the same frames laid out back to
+    back.  N = 4096 is the fused kernel (its own frame addressing), N = 1024 the transform + single-read pair."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, features
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    rng = np.random.default_rng(n)
+    frames, mp = 37, 32
+    rank, gamma = features.percentile_rank(n, 20.0), float(features.percentile_gamma(n, 20.0))
+
+    def run(plan, x, stride):
+        bufs = {}
+        sizes = {"iq": x.nbytes, "rows": frames * n * 4, "stats": frames * 16 * 8, "thr": frames * 8, "idx": frames * mp * 4, "cnt": frames * 4}
+        for k, sz in sizes.items():
+            bufs[k] = ctypes.c_void_p()
+            _ffi.check(lib.sdrk_dev_alloc(0, sz, ctypes.byref(bufs[k])))
+        try:
+            _ffi.check(lib.sdrk_memcpy_h2d(0, bufs["iq"], x.ctypes.data_as(ctypes.c_void_p), x.nbytes))
+            _ffi.check(lib.sdrk_frame_features_device(plan.handle, bufs["iq"], frames, stride, bufs["rows"], rank, ctypes.c_float(gamma),
+                                                      max(3, n // 300), mp, bufs["stats"], bufs["thr"], bufs["idx"], bufs["cnt"], None))
+            plan.sync()
+            host = {"rows": np.empty((frames, n), np.float32), "stats": np.empty((frames, 16)), "thr": np.empty(frames),
+                    "idx": np.empty((frames, mp), np.int32), "cnt": np.empty(frames, np.int32)}
+            for k, a in host.items():
+                _ffi.check(lib.sdrk_memcpy_d2h(0, a.ctypes.data_as(ctypes.c_void_p), bufs[k], a.nbytes))
+            return host
+        finally:
+            for b in bufs.values():
+                lib.sdrk_dev_free(0, b)
+
+    with SpectrumPlan(n, window="hann") as plan:
+        for hop in (n // 4, n - 1, n, n + 7, 3 * n):
+            stream = rand_c64(rng, n + (frames - 1) * hop, scale=25.0)
+            packed = np.stack([stream[r * hop: r * hop + n] for r in range(frames)])
+            a, b = run(plan, stream, hop), run(plan, packed.reshape(-1), n)
+            assert np.array_equal(a["rows"], b["rows"]), (n, hop)
+            assert np.array_equal(a["stats"], b["stats"]) and np.array_equal(a["thr"], b["thr"]), (n, hop)
+            assert np.array_equal(a["cnt"], b["cnt"]), (n, hop)
+            for r in range(frames):
+                k = min(int(a["cnt"][r]), mp)
+                assert np.array_equal(a["idx"][r, :k], b["idx"][r, :k]), (n, hop, r)
+            assert_db_parity(a["rows"], cpu_ref.spectrum_db(packed, window=np.hanning(n)), what=f"N={n} hop={hop}")
+
+
 def test_row_features_special_rows(pkg):
     """Edge cases of the reductions: the all-zero frame's -240 dB row (every value equal: sigma 0, flatness 1,
     no peaks), rows with -inf (eps = 0) and an all-NaN row (empty band sentinels -> 0 Hz, as the reference)."""
