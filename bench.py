@@ -10,7 +10,8 @@ N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
 one rank per GPU; rank g owns frames [g*2^20, (g+1)*2^20) of BASELINE.json config 4
 (frame-range sharding, weak scaling, no data-path collective: the only RCCL traffic
-is the barrier and the max-reduce of the elapsed time).
+is the barrier and the max-reduce of the elapsed time; if RCCL does not come up on
+every rank alike, those move to gloo and config.rendezvous_note says so).
 
 A "step" is one pass of the hot path over the rank's device-resident batch.  Rank 0
 prints ONE JSON line.  At N = 1 the same line also carries:
@@ -575,11 +576,31 @@ def main():
     backend = "nccl" if n_dev >= world else "gloo"
     if n_dev < world:
         args.placement_candidates = 1               # ranks share a GPU here: no probing with its memory
+    backend_note = None
     if "RANK" in os.environ:
         import torch.distributed as dist
         torch.cuda.set_device(dev)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            # the communicator is formed (and proven: one all-reduce) here, before the warm-up.  The data path has no
+            # collective, so a node whose RCCL does not come up can still be measured: if every rank fails the same
+            # way the barrier and the reductions of the times move to gloo, and the line says so.
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+                if os.environ.get("SDRK_BENCH_FAIL_NCCL"):           # rehearsal of the fallback below (tools only)
+                    raise RuntimeError("SDRK_BENCH_FAIL_NCCL is set")
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all-reduce of ones over {world} ranks gave {probe.item()}")
+            except Exception as e:                                   # noqa: BLE001 - reported in the line
+                backend_note = f"nccl did not come up ({type(e).__name__}: {str(e)[:160]}); barrier and reductions on gloo"
+                try:
+                    dist.destroy_process_group()
+                except Exception:                                    # noqa: BLE001
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo")          # same store (under torchrun it is the agent's): keys do not clash
         else:
             dist.init_process_group("gloo")
     red_dev = "cuda" if backend == "nccl" else "cpu"
@@ -761,6 +782,7 @@ def main():
                 "nfft": NFFT, "frames_per_gpu": frames, "window": args.window,
                 "sharding": f"frame-range x{world}, no collectives", "device": info,
                 "rendezvous_backend": (backend if dist is not None else None),
+                **({"rendezvous_note": backend_note} if backend_note else {}),
             },
             "hbm_peak_frac": round(value * 1e6 * ALGO_BYTES_PER_SAMPLE / 1e9 / (HBM_PEAK_GBPS * world), 4),
             "roofline": {
