@@ -1562,6 +1562,7 @@ int sdrk_waterfall_append_iq_device_async(sdrk_waterfall* wf, sdrk_plan* p, cons
                     p->nfft, p->device, wf->nfft, wf->device);
     if (n_frames == 0) return SDRK_OK;
     if (!d_iq) return fail(SDRK_ERR_INVALID, "d_iq is NULL");
+    if (frame_stride == 0 && n_frames > 1) return fail(SDRK_ERR_INVALID, "frame_stride must be >= 1 for more than one frame");
     HIP_TRY(hipSetDevice(wf->device));
     size_t skip = n_frames > (size_t)wf->maxlen ? n_frames - (size_t)wf->maxlen : 0;
     if (skip) wf_advance(wf, skip);

@@ -97,6 +97,7 @@ def cases():
     yield "waterfall_append_iq: NULL frames", lib.sdrk_waterfall_append_iq(wf, plan, NULL, 1, 4096)
     yield "waterfall_append_iq_device: plan of another length", lib.sdrk_waterfall_append_iq_device(wf, plan1k, d, 1, 1024)
     yield "waterfall_append_iq_device_async: NULL buffer", lib.sdrk_waterfall_append_iq_device_async(wf, plan, NULL, 1, 4096)
+    yield "waterfall_append_iq_device: stride 0 with two frames", lib.sdrk_waterfall_append_iq_device(wf, plan, d, 2, 0)
     yield "waterfall_read: NULL output", lib.sdrk_waterfall_read(wf, NULL, 1, byref(got))
     yield "waterfall_read_decimated: factor that does not divide", lib.sdrk_waterfall_read_decimated(wf, rp, 1, 3, 0, byref(got))
     yield "waterfall_read_decimated: factor 0", lib.sdrk_waterfall_read_decimated(wf, rp, 1, 0, 0, byref(got))
