@@ -7,29 +7,32 @@
 // adaptive threshold (:55) and the greedy peak list (:200-212).  The rule ladder (:69-122) and the
 // 12-frame smoothing (:125-139) are scalar application logic and stay with the caller.
 //
-// row_features_kernel<STAGE>  one workgroup per row; the row is read from HBM ONCE into LDS (STAGE,
-//   rows up to 32768 bins) and every scan of row_features_core.h — two reduction scans, the radix select
-//   of the order statistics (5 passes) and the peak scan — runs on the LDS copy: 4 B/bin of HBM traffic
-//   instead of the ~10 row reads of the first version.  Longer rows are scanned in place (L2-resident).
+// row_features_kernel<STAGE, SHORT, NCONST>  one workgroup per row; the row is read from HBM ONCE into LDS
+//   (STAGE, rows up to 32768 bins) and every scan of row_features_core.h runs on the LDS copy (rows of <= 4096
+//   bins: on a register copy of that): 4 B/bin of HBM traffic.  Longer rows are scanned in place (L2-resident).
+//   Three builds instead of one kernel that branches on the length: rows of exactly 4096 bins (the reference's
+//   frame; bounds checks fold, four workgroups per SIMD: 30 -> 22.6 ns per row), other short rows, long rows.
 // row_peaks_kernel            the peak scan alone, for caller-supplied thresholds (sdrk_row_peaks).
 // The N = 4096 transform can also run the same routine as its epilogue (fft4096.hip, EPI_FEATURES).
 #include "row_features_core.h"
 
 namespace sdrk {
 
-#ifndef RF_MIN_WAVES
-#define RF_MIN_WAVES 3   // workgroups per SIMD the register allocation aims at
-#endif
 constexpr int RF_STAGE_MAX = 32768;   // bins: 128 KiB of the 160 KiB LDS
 
-template <bool STAGE>
-__global__ __launch_bounds__(RF_THREADS, RF_MIN_WAVES) void row_features_kernel(const float* __restrict__ rows, size_t n_rows, int nfft,
+// SHORT rows (<= 4096 bins: the register-resident routine) are built for four workgroups per SIMD (<= 128 VGPRs, as
+// the fused kernel), longer rows (LDS / L2 scans, few registers needed, LDS-limited anyway) without a bound.
+// NCONST: the row length as a compile-time constant (4096, the reference's: bounds checks fold, 128 VGPRs without
+// spills) or 0 = the argument.
+template <bool STAGE, bool SHORT, int NCONST>
+__global__ __launch_bounds__(RF_THREADS, NCONST ? 4 : (SHORT ? 3 : 2)) void row_features_kernel(const float* __restrict__ rows, size_t n_rows, int nfft,
                                                                  RowFeatParams prm, double* __restrict__ stats,
                                                                  double* __restrict__ thr, int* __restrict__ idx,
                                                                  int* __restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) float rf_row[];
     __shared__ RowFeatShared sh;
     const int tid = threadIdx.x;
+    if (NCONST) nfft = NCONST;
     for (size_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
         const float* __restrict__ x = rows + r * (size_t)nfft;
         double* o_thr = thr ? thr + r : nullptr;
@@ -45,9 +48,9 @@ __global__ __launch_bounds__(RF_THREADS, RF_MIN_WAVES) void row_features_kernel(
                 for (int i = tid; i < nfft; i += RF_THREADS) rf_row[i] = x[i];
             }
             __syncthreads();
-            row_features_wg(rf_row, nfft, prm, sh, stats + r * 16, o_thr, o_idx, o_cnt);
+            row_features_wg<SHORT ? 1 : 2>(rf_row, nfft, prm, sh, stats + r * 16, o_thr, o_idx, o_cnt);
         } else {
-            row_features_wg(x, nfft, prm, sh, stats + r * 16, o_thr, o_idx, o_cnt);
+            row_features_wg<SHORT ? 1 : 2>(x, nfft, prm, sh, stats + r * 16, o_thr, o_idx, o_cnt);
         }
         __syncthreads();   // the staged row and the shared scratch are reused by the next row
     }
@@ -108,15 +111,21 @@ hipError_t launch_row_features(const float* d_rows, size_t n_rows, int nfft, int
     if (per_cu < 1) per_cu = 1;
     const size_t cap = (size_t)num_cus * per_cu;
     const unsigned grid = (unsigned)(n_rows < cap ? n_rows : cap);
-    if (stage) {
-        auto kern = row_features_kernel<true>;
+    if (nfft == 4096) {
+        hipLaunchKernelGGL((row_features_kernel<true, true, 4096>), dim3(grid), dim3(RF_THREADS), lds_bytes, s, d_rows, n_rows, nfft,
+                           prm, d_stats, d_thr, d_idx, d_cnt);
+    } else if (nfft <= 16 * RF_THREADS) {    // (always staged: <= 16 KiB)
+        hipLaunchKernelGGL((row_features_kernel<true, true, 0>), dim3(grid), dim3(RF_THREADS), lds_bytes, s, d_rows, n_rows, nfft,
+                           prm, d_stats, d_thr, d_idx, d_cnt);
+    } else if (stage) {
+        auto kern = row_features_kernel<true, false, 0>;
         static std::atomic<uint64_t> lds_ok{0};
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);
         if (e0 != hipSuccess) return e0;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(RF_THREADS), lds_bytes, s, d_rows, n_rows, nfft, prm, d_stats, d_thr,
                            d_idx, d_cnt);
     } else {
-        hipLaunchKernelGGL(row_features_kernel<false>, dim3(grid), dim3(RF_THREADS), 0, s, d_rows, n_rows, nfft, prm,
+        hipLaunchKernelGGL((row_features_kernel<false, false, 0>), dim3(grid), dim3(RF_THREADS), 0, s, d_rows, n_rows, nfft, prm,
                            d_stats, d_thr, d_idx, d_cnt);
     }
     return hipGetLastError();

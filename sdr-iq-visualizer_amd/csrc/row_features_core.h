@@ -852,7 +852,10 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
 // The whole measurement of one row by one 256-thread workgroup.  `x` points at n float32 values (LDS or global).
 // o_stats: 16 doubles; o_thr: 1 double; o_idx: max_peaks ints; o_cnt: 1 int (total peaks found, may exceed max_peaks).
 // o_idx / o_cnt / o_thr may be null (stats only).
-template <class RowPtr>
+// SIZE: 0 = either routine by n (the fused kernel passes a constant n and keeps one), 1 = the caller guarantees
+// n <= 16 * RF_THREADS, 2 = the caller guarantees n > 16 * RF_THREADS (row_features.hip builds one kernel per class,
+// so that the short-row kernel is not allocated registers for code it never runs).
+template <int SIZE = 0, class RowPtr>
 __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatParams& prm, RowFeatShared& sh,
                                                 double* __restrict__ o_stats, double* __restrict__ o_thr,
                                                 int* __restrict__ o_idx, int* __restrict__ o_cnt) {
@@ -861,7 +864,7 @@ __device__ __forceinline__ void row_features_wg(RowPtr x, int n, const RowFeatPa
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     __builtin_assume(tid >= 0 && tid < RF_THREADS);   // (the range survives the opaque copy: bounds checks against a constant n fold)
-    if (n <= 16 * RF_THREADS) rf_small(x, n, prm, sh, o_stats, o_thr, o_idx, o_cnt, tid);
+    if (SIZE == 1 || (SIZE == 0 && n <= 16 * RF_THREADS)) rf_small(x, n, prm, sh, o_stats, o_thr, o_idx, o_cnt, tid);
     else rf_large(x, n, prm, sh, o_stats, o_thr, o_idx, o_cnt, tid);
 }
 
