@@ -101,6 +101,14 @@ __device__ __forceinline__ float rf_pow10_tenth_f32_inrange(float v) {
     return ldexpf(__builtin_amdgcn_exp2f(f), (int)fminf(k, 300.0f));
 }
 
+// 10^(level/10) in float64 to ~1e-7 relative for any finite level (the scale of a sum taken relative to `level`):
+// the exponent is split in float64, 2^fraction comes from v_exp_f32, v_ldexp_f64 applies the integer part
+__device__ __forceinline__ double rf_pow10_tenth_f64(float level) {
+    const double t = (double)level * 0.33219280948873623479;
+    const double k = floor(t);
+    return ldexp((double)__builtin_amdgcn_exp2f((float)(t - k)), (int)k);
+}
+
 // sum of the per-wave totals of the waves before `wave` (four waves; branch-free: written as a loop over w < wave
 // the compiler does not know the trip count is <= 3 and emits an unrolled-by-8 loop with spills around it)
 __device__ __forceinline__ unsigned rf_waves_before(const unsigned* t, int wave) {
@@ -442,6 +450,29 @@ __device__ __forceinline__ void rf_large(RowPtr x, int n, const RowFeatParams& p
     const double mean = (sh.d[0] + sh.d[3] + sh.d[6] + sh.d[9]) / n;
     r.mean_p = (sh.d[1] + sh.d[4] + sh.d[7] + sh.d[10]) / n;
     r.mean_lp = (sh.d[2] + sh.d[5] + sh.d[8] + sh.d[11]) / n;
+    if (mx > 300.0f) {
+        // float32 overflows 10^(x/10) at 385 dB where the reference's float64 does not: sum p relative to the row's
+        // maximum and scale back in float64 (one more pass over a row nobody will ever measure)
+        double sq = 0.0;
+        int ncl = 0;
+        for (int i = tid; i < n; i += RF_THREADS) {
+            const float v = x[i];
+            const bool clip = v < -150.0f;
+            sq += clip ? 0.0 : (double)rf_pow10_tenth_f32(v - mx);
+            ncl += clip ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sq += __shfl_down(sq, off, 64);
+            ncl += __shfl_down(ncl, off, 64);
+        }
+        __syncthreads();
+        if (lane == 0) { sh.d2[wave] = sq; sh.i[28 + wave] = ncl; }
+        __syncthreads();
+        r.mean_p = ((sh.d2[0] + sh.d2[1] + sh.d2[2] + sh.d2[3]) * rf_pow10_tenth_f64(mx) +
+                    (double)(sh.i[28] + sh.i[29] + sh.i[30] + sh.i[31]) * 1e-15) / n;
+        __syncthreads();
+    }
 
     // scan B: central moments, occupied-band edges (thresholds in float32, as peak - float(drop) is)
     const float t3 = mx - 3.0f, t10 = mx - 10.0f, t20 = mx - 20.0f;
@@ -551,6 +582,19 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // Values past 300 dB (|X| > 1e15): float32 overflows 10^(x/10) at 385 dB where the reference's float64 does not.
+    // Such a wave (none of any real row) sums p once more, relative to its own maximum, and scales the sum back in
+    // float64 below.
+    float level = 0.0f;
+    if (__any(mx > 300.0f)) {
+        level = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rf_wave_scan_max(mx)), 63));
+        sp = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float v = xv[j];
+            if (tid + RF_THREADS * j < n && !(v < -150.0f)) sp += (double)rf_pow10_tenth_f32(v - level);
+        }
+    }
     double sx = su + sc;
     // the wave's maximum (NaNs skipped, as a running `v > mx` does), then its first bin: bin i = 256 j + 64 wave +
     // lane, so the first set bit of the first non-empty ballot over j.  (A wave whose maximum stayed -inf has no
@@ -571,6 +615,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     } else {
         su = sx;
     }
+    if (level != 0.0f) sp = sp * rf_pow10_tenth_f64(level) + (double)nclip * 1e-15;   // (the clipped bins' 1e-15 each)
     if (lane == 63) {
         sh.f[wave] = mx; sh.i[wave] = amx; sh.i[28 + wave] = nclip;
         sh.d[wave * 3] = sx; sh.d[wave * 3 + 1] = sp; sh.d[wave * 3 + 2] = su;

@@ -221,6 +221,26 @@ def test_oracle_row_features_match_reference_classifier_helpers(golden):
         assert np.array_equal(f["peak_idx"], g[f"{k}/peak_idx"]), k
 
 
+def test_oracle_row_features_match_reference_on_corner_rows(golden):
+    """The same restatement where realistic rows never go: 33 rows chosen for the corners of the device reductions
+    (lengths 16 ... 33000, ties, cliffs at the percentile, -inf bins, an all-NaN row, the all-zero frame's constant
+    row, overflowing and fully clipped flatness), against what the reference's helpers returned for them
+    (oracle/make_golden_corner_rows.py).  Bit for bit, NaN where the reference gives NaN."""
+    import warnings
+    g = golden["ref_classifier_corner_rows"]
+    fs, fc = g["fs_fc"]
+    for k in (str(n) for n in g["names"]):
+        p = g[f"{k}/power_db"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            f = cpu_ref.row_features(cpu_ref.freq_axis(p.shape[0], fs, fc), p)
+        got = np.array([f["noise_floor_db"], f["snr_db"], f["bandwidth_hz_3db"], f["bandwidth_hz_10db"],
+                        f["bandwidth_hz_20db"], f["spectral_flatness"], f["spectral_kurtosis"],
+                        f["adaptive_threshold_db"], f["peak_spacing_std_hz"]])
+        assert np.array_equal(got, g[f"{k}/scalars"], equal_nan=True), (k, got, g[f"{k}/scalars"])
+        assert np.array_equal(f["peak_idx"], g[f"{k}/peak_idx"]), k
+
+
 def test_percentile_rank_and_interpolation_mirror_numpy():
     from sdr_iq_visualizer_amd import features
     rng = np.random.default_rng(9)

@@ -678,6 +678,34 @@ def test_row_features_vs_reference_classifier_helpers(pkg, golden):
     assert np.array_equal(capped["peak_idx"], g["pluto12_noise/peak_idx"][:10])
 
 
+def test_row_features_vs_reference_on_corner_rows(pkg, golden):
+    """f1 where realistic rows never go: the device reductions against what the REFERENCE's helpers returned for 33
+    corner rows (oracle/make_golden_corner_rows.py: lengths 16 ... 33000, more than 64 values tied at the percentile,
+    cliffs, -inf bins, all-NaN, the constant -240.00002 dB row, combs at and just under the peak spacing, plateaus,
+    maxima on the edge bins, flatness that overflows or is clipped entirely).  Exact where the reference is exact,
+    NaN where it is NaN."""
+    import warnings
+    from sdr_iq_visualizer_amd import features
+    g = golden["ref_classifier_corner_rows"]
+    fs, fc = g["fs_fc"]
+
+    def same(a, b, tol=0.0):
+        return (np.isnan(a) and np.isnan(b)) or a == b or (np.isfinite(a) and np.isfinite(b) and abs(a - b) <= tol * max(1.0, abs(b)))
+
+    for k in (str(n) for n in g["names"]):
+        p, s = g[f"{k}/power_db"], g[f"{k}/scalars"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = features.row_features(p, cpu_ref.freq_axis(p.shape[0], fs, fc))
+        assert same(got["noise_floor_db"], s[0]) and same(got["snr_db"], s[1]), (k, got["noise_floor_db"], s[0])
+        assert (got["bandwidth_hz_3db"], got["bandwidth_hz_10db"], got["bandwidth_hz_20db"]) == (s[2], s[3], s[4]), k
+        assert same(got["spectral_flatness"], s[5], FLATNESS_TOL), (k, got["spectral_flatness"], s[5])
+        assert same(got["spectral_kurtosis"], s[6], 1e-9), (k, got["spectral_kurtosis"], s[6])
+        assert same(got["adaptive_threshold_db"], s[7]), (k, got["adaptive_threshold_db"], s[7])
+        assert np.array_equal(got["peak_idx"], g[f"{k}/peak_idx"]) and got["peak_count"] == len(g[f"{k}/peak_idx"]), k
+        assert same(got["peak_spacing_std_hz"], s[8]), k
+
+
 def test_row_features_other_sizes_vs_oracle(pkg):
     from sdr_iq_visualizer_amd import features
     rng = np.random.default_rng(17)

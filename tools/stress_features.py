@@ -8,7 +8,7 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from oracle import cpu_ref
 from sdr_iq_visualizer_amd import features
 
-kinds = ["noise", "quantised", "tone", "steps", "wide", "holes", "const_tail", "ramp"]
+kinds = ["noise", "quantised", "tone", "steps", "wide", "holes", "const_tail", "ramp", "huge"]
 
 
 def run(cases, seed):
@@ -36,6 +36,8 @@ def one_case(c, rng, done):
             x[rng.random(n) < 0.05] = -np.inf
         elif kind == "const_tail":
             x[n // 2:] = x[0]
+        elif kind == "huge":                          # past float32's 10^(x/10) range (385 dB) in part of the row
+            x[rng.random(n) < 0.3] += np.float32(rng.uniform(400, 3000))
         elif kind == "ramp":
             x = np.linspace(-80, 5, n).astype(np.float32) + (rng.standard_normal(n) * 0.01).astype(np.float32)
         freqs = cpu_ref.freq_axis(n, 2e6, 1e9)
