@@ -586,6 +586,27 @@ def test_sharding_kernels_with_more_than_64k_lds_on_every_device(pkg, n, batch):
 
 # ---- "next" rows on the GPU ------------------------------------------------
 
+def test_welch_psd_randomised(pkg):
+    """Averaged periodograms (scripts/process_sigmf_data.py:188-189) for random segment lengths (powers of two, odd
+    lengths, the two-pass sizes), hops with gaps and overlaps, 1 ... 60 segments, both windows, shifted or not,
+    against the oracle's float64 restatement of mlab.psd: within 1e-5 of the largest bin."""
+    rng = np.random.default_rng(188)
+    for case in range(28):
+        n = int(rng.choice([64, 256, 1000, 1024, 4096, 8192, 65536]))
+        hop = n if rng.random() < 0.4 else int(rng.integers(1, 2 * n + 1))
+        segs = int(rng.integers(1, 61 if n <= 8192 else 9))
+        L = n + (segs - 1) * hop + int(rng.integers(0, hop))
+        window = "hann" if rng.random() < 0.6 else None
+        shift = bool(rng.random() < 0.7)
+        fs = float(rng.choice([1e6, 2.4e6, 61.44e6]))
+        x = rand_c64(rng, L, scale=float(rng.uniform(0.01, 300)))
+        x += (rng.uniform(1, 100) * np.exp(2j * np.pi * rng.uniform(-0.5, 0.5) * np.arange(L))).astype(np.complex64)
+        got = pkg.welch_psd(x, n, fs, hop=hop, window=window, shift=shift)
+        ref = cpu_ref.welch_psd(x, n, fs, hop=hop, window=None if window else np.ones(n), shift=shift)
+        assert got.dtype == np.float32 and got.shape == (n,)
+        assert np.abs(got - ref).max() <= 1e-5 * ref.max(), (case, n, hop, segs, window, shift, float(np.abs(got - ref).max() / ref.max()))
+
+
 def test_welch_psd_vs_mlab_golden(pkg, golden):
     """Offline PSD of scripts/process_sigmf_data.py:188-189 (mlab.psd, NFFT=1024, Hann)."""
     g = golden["ref_welch"]
