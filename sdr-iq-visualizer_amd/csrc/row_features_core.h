@@ -20,14 +20,18 @@
 // around the row's mean (a monotone float32 map, so bin order is value order), a 256-thread prefix scan to the
 // bins that hold ranks r and r+1, and an exact ranking of the handful of values inside them (<= 64, else the
 // radix select below takes over, as it does for rows with NaN / inf values or a percentile more than 64 dB off
-// the mean).  Longer rows: exact radix select on the float32 keys, 8 bits per pass (no sort); the second
+// the mean).  Longer rows: the same value histogram refined level by level (rf_select_hist), with the exact radix
+// select on the float32 keys, 8 bits per pass (no sort), behind it for the same exceptional rows; the second
 // statistic (rank+1) costs one more pass: it equals sorted[rank] when more than rank+1 elements are <= it, else
 // it is the smallest larger element.
 //
 // Sums: mean, variance and fourth moment in float64 exactly as before.  mean p: 10^(x/10) per bin as float32
 // v_exp_f32 on an exactly reduced argument (relative error ~1e-7 per term, random sign), accumulated in float64;
 // mean ln p = (ln10/10) * mean x needs no transcendental.  (BASELINE.json asks for 1e-5; the float64 degree-10
-// polynomial this replaces held 1e-11 at ~6x the cost.)
+// polynomial this replaces held 1e-11 at ~6x the cost.)  A wave that holds values past 300 dB (float32 overflows
+// 10^(x/10) at 385, the reference's float64 does not) sums p relative to its maximum and scales back in float64.
+// The adaptive threshold's float32 steps are written under `#pragma clang fp contract(off)` (rf_mul_f32 ...):
+// numpy rounds after every operation, and HIP's __fmul_rn / __fadd_rn do not stop hipcc from fusing them.
 #pragma once
 #include "kernels.h"
 
