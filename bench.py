@@ -484,6 +484,25 @@ def feature_reductions(lib, _ffi, SpectrumPlan, features, dev, n_frames=1 << 18)
                 "ms": round(t * 1e3, 3), "rows_per_s": round(n_frames / t),
                 "what": "fft4096_kernel writes the rows, row_features_kernel reads them once (staged in LDS); "
                         "includes the D2H of the per-row results (stats, threshold, 64 peak slots)"}
+        # the numpy boundary of the same measurement (PCIe inclusive, never `value`): host IQ in, arrays of results out
+        import sdr_iq_visualizer_amd as pkg
+        b = 1 << 15                                                   # 1 GiB of IQ
+        x = pkg.pinned_empty((b, n), np.complex64)
+        x[...] = (np.random.default_rng(5).standard_normal((b, 2 * n), dtype=np.float32) * 200).view(np.complex64)
+        pageable = np.array(x)
+        rec = {"frames": b, "max_peaks": max_peaks,
+               "what": "features.frame_features(complex64 numpy (B,4096), as_arrays=True): chunks staged through pinned slots "
+                       "(pageable) or DMA'd from the caller's pinned array, fused kernel per chunk, results back at the end"}
+        for name, arr in (("pageable", pageable), ("pinned", x)):
+            features.frame_features(arr[:2048], 1e6, 0.0, window="hann", device=dev, max_peaks=max_peaks, as_arrays=True)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                features.frame_features(arr, 1e6, 0.0, window="hann", device=dev, max_peaks=max_peaks, as_arrays=True)
+                ts.append(time.perf_counter() - t0)
+            t = _median(ts)
+            rec[name] = {"ms_per_call": round(t * 1e3, 2), "rows_per_s": round(b / t), "input_GBps": round(b * n * 8 / t / 1e9, 2)}
+        out["numpy_boundary"] = rec
         return out
     finally:
         for b in bufs.values():

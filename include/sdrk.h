@@ -242,7 +242,8 @@ int sdrk_synth_fill(int device, uint32_t seed, uint64_t first_frame, size_t n_fr
  *   (`rank`, `gamma` = floor and fraction of float32(nfft-1)*float32(q/100)).
  * peaks: strict local maxima above the threshold, accepted left to right when
  *   >= min_distance bins after the previous accepted one (:200-212).
- *   out_idx: n_rows*max_peaks int32 (first max_peaks peaks of each row),
+ *   out_idx: n_rows*max_peaks int32 (first max_peaks peaks of each row; the host entry points
+ *   sdrk_row_features / sdrk_frame_features_host fill the unused slots with -1),
  *   out_count: n_rows int32 (may exceed max_peaks: the total found).
  *
  * sdrk_row_features: everything in ONE launch that reads each row from HBM once (rows up
@@ -264,7 +265,8 @@ int sdrk_row_peaks(int device, const float* rows, int rows_on_device, size_t n_r
  * of the transform kernel itself: the row exists only in LDS unless the caller passes a
  * buffer for it.  _device: every pointer is device memory, asynchronous on `stream` (or
  * the plan's stream); d_out_db, d_thr, d_idx/d_count may be NULL.  _host: host pointers,
- * blocking; out_db (the rows) may be NULL. */
+ * blocking; out_db (the rows) may be NULL; batches of more than 32 MiB of IQ stream through the
+ * pinned staging of sdrk_exec_host in chunks (pinned caller arrays are read in place). */
 int sdrk_frame_features_device(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames,
                                size_t frame_stride, float* d_out_db, int rank, float gamma,
                                int min_distance, int max_peaks, double* d_stats, double* d_thr,

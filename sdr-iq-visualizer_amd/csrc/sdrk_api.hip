@@ -1329,6 +1329,7 @@ int sdrk_row_features(int device, const float* rows, int rows_on_device, size_t 
         HIP_TRY(hipMemcpy(base + L.rows_off, rows, n_rows * (size_t)nfft * sizeof(float), hipMemcpyHostToDevice));
         d_rows = reinterpret_cast<const float*>(base + L.rows_off);
     }
+    if (peaks) HIP_TRY(hipMemsetAsync(base + L.idx_off, 0xFF, n_rows * (size_t)max_peaks * sizeof(int), nullptr));   // unused slots: -1
     hipError_t e = sdrk::launch_row_features(d_rows, n_rows, nfft, rank, gamma, min_distance, max_peaks,
                                              reinterpret_cast<double*>(base + L.stats_off),
                                              reinterpret_cast<double*>(base + L.thr_off),
@@ -1441,8 +1442,6 @@ int sdrk_frame_features_host(sdrk_plan* p, const void* iq, size_t n_frames, size
     HIP_TRY(hipSetDevice(p->device));
     const size_t nfft = (size_t)p->nfft;
     const size_t in_bytes = ((n_frames - 1) * frame_stride + nfft) * sizeof(float2);
-    st = grow(p->device, &p->d_in, &p->in_cap, in_bytes);
-    if (st != SDRK_OK) return st;
     // results (and the rows, when the caller wants them or the frame length has no fused kernel) in a second
     // staging buffer that only grows
     const bool need_rows = out_db != nullptr;
@@ -1451,14 +1450,73 @@ int sdrk_frame_features_host(sdrk_plan* p, const void* iq, size_t n_frames, size
     st = grow(p->device, &fbuf, &p->feat_cap, L.total);
     if (st != SDRK_OK) return st;
     char* base = static_cast<char*>(fbuf);
-    HIP_TRY(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
-    st = sdrk_frame_features_device(p, p->d_in, n_frames, frame_stride,
-                                    need_rows ? reinterpret_cast<float*>(base + L.rows_off) : nullptr, rank, gamma,
-                                    min_distance, max_peaks, reinterpret_cast<double*>(base + L.stats_off),
-                                    reinterpret_cast<double*>(base + L.thr_off),
-                                    peaks ? reinterpret_cast<int32_t*>(base + L.idx_off) : nullptr,
-                                    peaks ? reinterpret_cast<int32_t*>(base + L.cnt_off) : nullptr, nullptr);
-    if (st != SDRK_OK) return st;
+    float* d_rows = need_rows ? reinterpret_cast<float*>(base + L.rows_off) : nullptr;
+    double* d_stats = reinterpret_cast<double*>(base + L.stats_off);
+    double* d_thr = reinterpret_cast<double*>(base + L.thr_off);
+    int32_t* d_idx = peaks ? reinterpret_cast<int32_t*>(base + L.idx_off) : nullptr;
+    int32_t* d_cnt = peaks ? reinterpret_cast<int32_t*>(base + L.cnt_off) : nullptr;
+    if (peaks) HIP_TRY(hipMemsetAsync(d_idx, 0xFF, n_frames * (size_t)max_peaks * sizeof(int), p->stream));        // unused slots: -1
+    if (in_bytes <= 2 * HOST_CHUNK_BYTES) {
+        st = grow(p->device, &p->d_in, &p->in_cap, in_bytes);
+        if (st != SDRK_OK) return st;
+        HIP_TRY(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
+        st = sdrk_frame_features_device(p, p->d_in, n_frames, frame_stride, d_rows, rank, gamma, min_distance, max_peaks,
+                                        d_stats, d_thr, d_idx, d_cnt, nullptr);
+        if (st != SDRK_OK) return st;
+    } else {
+        // Large batches: the frames go through the pinned slots of the sdrk_exec_host pipeline in ~16 MiB chunks —
+        // helper threads stage chunk c+1 (or the copy engine reads the caller's pinned array directly) while chunk
+        // c crosses PCIe and chunk c-1 is measured.  The per-row results stay on the device until the end (they are
+        // ~1 % of the input).
+        if (!p->s_h2d) {
+            HIP_TRY(hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking));
+        }
+        const size_t stride_bytes = (frame_stride ? frame_stride : 1) * sizeof(float2);
+        size_t per = HOST_CHUNK_BYTES / stride_bytes;
+        if (per < 1) per = 1;
+        const size_t chunk_in = ((per - 1) * frame_stride + nfft) * sizeof(float2);
+        const bool in_pinned = pinned_ranges().covers(iq, in_bytes);
+        sdrk::CopyPool& pool = sdrk::CopyPool::get();
+        size_t c = 0;
+        for (size_t f0 = 0; f0 < n_frames; f0 += per, ++c) {
+            HostSlot& s = p->slot[c % HOST_SLOTS];
+            const size_t nf = n_frames - f0 < per ? n_frames - f0 : per;
+            const size_t cin = ((nf - 1) * frame_stride + nfft) * sizeof(float2);
+            hipError_t e = hipSuccess;
+            if (s.busy) {                                         // chunk c - HOST_SLOTS: measured, its staging is free
+                e = hipEventSynchronize(s.ev_k);
+                s.busy = false;
+            }
+            if (e == hipSuccess) {
+                st = slot_reserve(p, s, chunk_in, 0);
+                if (st != SDRK_OK) { slots_abandon(p); return st; }
+                const void* src = static_cast<const float2*>(iq) + f0 * frame_stride;
+                if (!in_pinned) {
+                    pool.copy(s.h_in, src, cin);
+                    src = s.h_in;
+                }
+                e = hipMemcpyAsync(s.d_in, src, cin, hipMemcpyHostToDevice, p->s_h2d);
+            }
+            if (e == hipSuccess) e = hipEventRecord(s.ev_in, p->s_h2d);
+            if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, s.ev_in, 0);
+            if (e != hipSuccess) {
+                slots_abandon(p);
+                return fail(SDRK_ERR_HIP, "feature pipeline failed: %s", hipGetErrorString(e));
+            }
+            st = sdrk_frame_features_device(p, s.d_in, nf, frame_stride, d_rows ? d_rows + f0 * nfft : nullptr, rank, gamma,
+                                            min_distance, max_peaks, d_stats + f0 * 16, d_thr + f0,
+                                            d_idx ? d_idx + f0 * (size_t)max_peaks : nullptr, d_cnt ? d_cnt + f0 : nullptr, nullptr);
+            if (st != SDRK_OK) { slots_abandon(p); return st; }
+            e = hipEventRecord(s.ev_k, p->stream);
+            if (e != hipSuccess) {
+                slots_abandon(p);
+                return fail(SDRK_ERR_HIP, "feature pipeline failed: %s", hipGetErrorString(e));
+            }
+            s.busy = true;
+            s.user_out = nullptr;
+        }
+    }
     HIP_TRY(hipMemcpyAsync(out_stats, base + L.stats_off, n_frames * 16 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     if (out_thr) HIP_TRY(hipMemcpyAsync(out_thr, base + L.thr_off, n_frames * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     if (peaks) {
@@ -1468,6 +1526,7 @@ int sdrk_frame_features_host(sdrk_plan* p, const void* iq, size_t n_frames, size
     if (need_rows)
         HIP_TRY(hipMemcpyAsync(out_db, base + L.rows_off, n_frames * nfft * sizeof(float), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    for (auto& s : p->slot) s.busy = false;                      // the pipelined form's chunks are all through
     return fused_check(p);
 }
 

@@ -111,15 +111,70 @@ def _assemble(stats, thr, idx, cnt, nfft: int, freqs, percentile: float, max_pea
     return out
 
 
+def _assemble_arrays(stats, thr, idx, cnt, nfft: int, freqs, percentile: float, max_peaks: int) -> dict:
+    """The same quantities as ``_assemble`` for all rows at once: a dict of arrays (one entry per row), no per-row
+    Python objects — for batches of thousands of rows, where building a dict per row costs more than measuring it."""
+    n_rows = stats.shape[0]
+    mx32 = stats[:, 0].astype(np.float32)
+    nf32 = _percentile_from_order_stats(nfft, percentile, stats[:, 1], stats[:, 2])
+    with np.errstate(all="ignore"):
+        sigma = np.sqrt(stats[:, 4])
+        kurt = np.where(sigma < 1e-9, 0.0, stats[:, 5] / (stats[:, 4] * stats[:, 4]))
+        out = {
+            "max_db": mx32.astype(np.float64),
+            "argmax": stats[:, 14].astype(np.int64),
+            "noise_floor_db": nf32.astype(np.float64),
+            "snr_db": (mx32 - nf32).astype(np.float64),                                        # :46 (float32)
+            "spectral_flatness": np.clip(np.exp(stats[:, 6]) / stats[:, 7], 0.0, 1.0),       # :186-189
+            "spectral_kurtosis": kurt,                                                        # :195-198
+            "adaptive_threshold_db": np.asarray(thr, dtype=np.float64),
+            "peak_count": np.asarray(cnt, dtype=np.int64),
+        }
+    # (rows, max_peaks): row r holds min(peak_count[r], max_peaks) indices, then -1 (the host entry points clear the table)
+    held = np.minimum(out["peak_count"], max_peaks)
+    out["peak_idx"] = idx
+    lo = stats[:, (8, 10, 12)].astype(np.int64)
+    hi = stats[:, (9, 11, 13)].astype(np.int64)
+    for j, name in enumerate(("3db", "10db", "20db")):
+        out[f"occupied_bins_{name}"] = np.stack([lo[:, j], hi[:, j]], axis=1)
+    if freqs is not None:
+        f = np.asarray(freqs, dtype=np.float64)
+        ok = (0 <= lo) & (lo <= hi) & (hi < nfft)                  # an all-NaN row has first > last: 0 Hz (:166-168)
+        bw = np.where(ok, f[np.clip(hi, 0, nfft - 1)] - f[np.clip(lo, 0, nfft - 1)], 0.0)
+        for j, name in enumerate(("3db", "10db", "20db")):
+            out[f"bandwidth_hz_{name}"] = bw[:, j]
+        # np.std(np.diff(f[peaks])) per row (:214-219), 0 for fewer than three peaks: masked two-pass form
+        # (few temporaries: at 32768 rows x 64 slots every extra pass over the table costs as much as a millisecond
+        # of PCIe time)
+        k = held
+        if max_peaks > 1:
+            valid = np.arange(max_peaks - 1)[None, :] < (k[:, None] - 1)
+            pf = f.take(idx, mode="clip")
+            d = pf[:, 1:] - pf[:, :-1]
+            d *= valid
+            m = np.maximum(k - 1, 1)
+            mean = d.sum(axis=1) / m
+            d -= mean[:, None]
+            d *= valid
+            var = np.einsum("ij,ij->i", d, d) / m
+        else:
+            var = np.zeros(n_rows)
+        out["peak_spacing_std_hz"] = np.where(k >= 3, np.sqrt(var), 0.0)
+        out["peak_density"] = out["peak_count"] / max(nfft, 1)
+    return out
+
+
 def _result_arrays(n_rows: int, max_peaks: int):
     return (np.empty((n_rows, _STATS), dtype=np.float64), np.empty(n_rows, dtype=np.float64),
             np.empty((n_rows, max_peaks), dtype=np.int32), np.empty(n_rows, dtype=np.int32))
 
 
-def row_features(power_db, freqs=None, *, device: int = 0, percentile: float = 20.0, max_peaks: int = 4096):
+def row_features(power_db, freqs=None, *, device: int = 0, percentile: float = 20.0, max_peaks: int = 4096,
+                 as_arrays: bool = False):
     """Features of one ``power_db`` row ``(N,)`` -> dict, or of rows ``(R, N)`` -> list of dicts.  One kernel launch
     that reads each row once (``sdrk_row_features``); ``power_db`` may be a host array or ``(device_pointer, n_rows,
-    nfft)`` for rows already in HBM."""
+    nfft)`` for rows already in HBM.  ``as_arrays=True``: one dict of arrays (entry r = row r) instead of a dict per
+    row."""
     _ffi.require_device(device)
     if isinstance(power_db, tuple):
         ptr, n_rows, nfft = c_void_p(int(power_db[0])), int(power_db[1]), int(power_db[2])
@@ -138,16 +193,21 @@ def row_features(power_db, freqs=None, *, device: int = 0, percentile: float = 2
                                   max(3, nfft // 300), max_peaks,                                   # :56
                                   stats.ctypes.data_as(c_void_p), thr.ctypes.data_as(c_void_p),
                                   idx.ctypes.data_as(c_void_p), cnt.ctypes.data_as(c_void_p)))
+    if as_arrays:
+        return _assemble_arrays(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
     res = _assemble(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
     return res[0] if one else res
 
 
 def frame_features(samples, sample_rate: float, center_freq: float, *, window=None, eps: float = 1e-12,
-                   device: int = 0, percentile: float = 20.0, max_peaks: int = 4096, return_rows: bool = False):
+                   device: int = 0, percentile: float = 20.0, max_peaks: int = 4096, return_rows: bool = False,
+                   as_arrays: bool = False):
     """IQ frame(s) -> features without the rows leaving the device (streamer.py:119,121 then classifier.py:163-212).
     For 4096-sample frames — the reference's buffer size — the reductions are the epilogue of the transform kernel
     itself and the row exists only on chip; other lengths run the transform and one single-read reduction launch.
-    ``return_rows=True`` also returns the ``power_db`` rows (then they are written once and copied back)."""
+    ``return_rows=True`` also returns the ``power_db`` rows (then they are written once and copied back);
+    ``as_arrays=True`` returns one dict of arrays instead of a dict per frame (large batches; pass a small ``max_peaks``,
+    the peak table is ``(frames, max_peaks)``)."""
     from .spectrum import _as_c64, _cached_plan, freq_axis
     x = _as_c64(samples)
     one = x.ndim == 1
@@ -166,8 +226,11 @@ def frame_features(samples, sample_rate: float, center_freq: float, *, window=No
                                              stats.ctypes.data_as(c_void_p), thr.ctypes.data_as(c_void_p),
                                              idx.ctypes.data_as(c_void_p), cnt.ctypes.data_as(c_void_p),
                                              rows.ctypes.data_as(c_void_p) if rows is not None else None))
-    res = _assemble(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
-    res = res[0] if one else res
+    if as_arrays:
+        res = _assemble_arrays(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
+    else:
+        res = _assemble(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
+        res = res[0] if one else res
     if return_rows:
         return res, (rows[0] if one else rows)
     return res

@@ -839,6 +839,35 @@ def test_frame_features_device_strides(pkg, n):
             assert_db_parity(a["rows"], cpu_ref.spectrum_db(packed, window=np.hanning(n)), what=f"N={n} hop={hop}")
 
 
+@pytest.mark.parametrize("n,frames", [(4096, 2500), (1024, 9000)])
+def test_frame_features_large_batches_are_pipelined_and_equal(pkg, n, frames):
+    """Batches of more than 32 MiB of IQ go through the pinned staging slots in chunks (sdrk_frame_features_host);
+    the array form of the results (`as_arrays=True`) equals the per-frame dicts of small calls on the same frames,
+    from pageable and from pinned input alike, and the returned rows equal the plain transform's."""
+    from sdr_iq_visualizer_amd import features
+    rng = np.random.default_rng(n + frames)
+    x = rand_c64(rng, frames, n, scale=40.0)
+    x[:, :] += (300 * np.exp(2j * np.pi * rng.uniform(-0.4, 0.4, (frames, 1)) * np.arange(n)[None, :])).astype(np.complex64)
+    fs, fc = 2e6, 1e9
+    big, rows = features.frame_features(x, fs, fc, window="hann", max_peaks=48, return_rows=True, as_arrays=True)
+    assert np.array_equal(rows, pkg.spectrum_db(x, window="hann"))
+    xp = pkg.pinned_empty(x.shape, np.complex64)
+    xp[...] = x
+    pinned = features.frame_features(xp, fs, fc, window="hann", max_peaks=48, as_arrays=True)
+    for key, a in big.items():
+        assert np.array_equal(a, pinned[key], equal_nan=True), key
+    picks = np.unique(np.concatenate([[0, 1, frames - 1], rng.integers(0, frames, 40)]))
+    small = features.frame_features(x[picks], fs, fc, window="hann", max_peaks=48)
+    for j, r in enumerate(picks):
+        for key in ("max_db", "argmax", "noise_floor_db", "snr_db", "spectral_flatness", "spectral_kurtosis", "adaptive_threshold_db",
+                    "peak_count", "bandwidth_hz_3db", "bandwidth_hz_10db", "bandwidth_hz_20db", "peak_density"):
+            assert small[j][key] == big[key][r], (key, r)
+        k = min(small[j]["peak_count"], 48)
+        assert np.array_equal(small[j]["peak_idx"], big["peak_idx"][r, :k]), r
+        assert abs(small[j]["peak_spacing_std_hz"] - big["peak_spacing_std_hz"][r]) <= 1e-9 * max(1.0, small[j]["peak_spacing_std_hz"]), r
+        assert small[j]["occupied_bins_20db"] == tuple(big["occupied_bins_20db"][r]), r
+
+
 def test_row_features_special_rows(pkg):
     """Edge cases of the reductions: the all-zero frame's -240 dB row (every value equal: sigma 0, flatness 1,
     no peaks), rows with -inf (eps = 0) and an all-NaN row (empty band sentinels -> 0 Hz, as the reference)."""
