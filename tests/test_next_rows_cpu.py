@@ -241,6 +241,18 @@ def test_oracle_row_features_match_reference_on_corner_rows(golden):
         assert np.array_equal(f["peak_idx"], g[f"{k}/peak_idx"]), k
 
 
+def test_freq_axis_equals_numpy_expression_for_random_lengths_and_rates():
+    """streamer.py:120, `fftshift(fftfreq(N, 1/fs)) + fc`: the host axis equals numpy's expression bit for bit for
+    odd and even lengths, powers of two up to 2^20, and arbitrary rates and centre frequencies."""
+    import sdr_iq_visualizer_amd as pkg
+    rng = np.random.default_rng(1)
+    for t in range(600):
+        n = int(rng.integers(1, 5000)) if t % 3 else int(2 ** rng.integers(1, 21))
+        fs = float(rng.choice([1e6, 2.4e6, 61.44e6, 20e6, rng.uniform(1e3, 1e9)]))
+        fc = float(rng.choice([0.0, 2.4e9, 100e6, rng.uniform(0, 6e9)]))
+        assert np.array_equal(pkg.freq_axis(n, fs, fc), np.fft.fftshift(np.fft.fftfreq(n, 1 / fs)) + fc), (n, fs, fc)
+
+
 def test_percentile_rank_and_interpolation_mirror_numpy():
     from sdr_iq_visualizer_amd import features
     rng = np.random.default_rng(9)
