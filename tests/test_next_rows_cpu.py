@@ -241,6 +241,62 @@ def test_oracle_row_features_match_reference_on_corner_rows(golden):
         assert np.array_equal(f["peak_idx"], g[f"{k}/peak_idx"]), k
 
 
+def test_oracle_equals_reference_helpers_on_random_rows():
+    """Where the reference is present (the build container; it never travels), the oracle's row_features is run next to
+    the reference's own helpers on 400 random rows of the kinds tools/stress_features.py and stress_fused.py use
+    (noise, ties, tones, cliffs, far-off percentiles, -inf bins, constant tails, ramps, values past 385 dB; lengths
+    16 ... 20000): every scalar and every peak list identical.  This is what lets the GPU stress tools use the oracle
+    as their checker for thousands of rows."""
+    import os
+    import sys
+    import warnings
+    ref_root = os.environ.get("SDRK_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "app", "processing")):
+        pytest.skip("the reference is not present on this machine")
+    sys.path.insert(0, ref_root)
+    try:
+        from app.processing import classifier as C
+    finally:
+        sys.path.remove(ref_root)
+    rng = np.random.default_rng(400)
+    kinds = ["noise", "quantised", "tone", "steps", "wide", "holes", "const_tail", "ramp", "huge"]
+    for c in range(400):
+        n = int(rng.choice([16, 64, 100, 257, 1000, 2048, 4096, 4097, 8192, 20000]))
+        kind = kinds[c % len(kinds)]
+        x = (rng.standard_normal(n) * rng.uniform(1, 9) + rng.uniform(-120, 60)).astype(np.float32)
+        if kind == "quantised":
+            x = (np.round(x * 2) / 2).astype(np.float32)
+        elif kind == "tone":
+            x[rng.integers(0, n, 3)] += np.float32(90)
+        elif kind == "steps":
+            x[: max(1, n // 5 + int(rng.integers(-3, 4)))] -= np.float32(150)
+        elif kind == "wide":
+            x[rng.random(n) < 0.8] += np.float32(70)
+        elif kind == "holes":
+            x[rng.random(n) < 0.05] = -np.inf
+        elif kind == "const_tail":
+            x[n // 2:] = x[0]
+        elif kind == "ramp":
+            x = np.linspace(-80, 5, n).astype(np.float32) + (rng.standard_normal(n) * 0.01).astype(np.float32)
+        elif kind == "huge":
+            x[rng.random(n) < 0.3] += np.float32(rng.uniform(400, 3000))
+        freqs = cpu_ref.freq_axis(n, 20e6, 2.4e9)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            nf = C._estimate_noise_floor(x)
+            snr = float(np.max(x) - nf)
+            thr = max(nf + 5.0, np.max(x) - 0.9 * snr + 5.0)
+            pk = C._find_peaks(x, threshold_db=thr, min_distance_bins=max(3, len(x) // 300))
+            ref = np.array([nf, snr, C._occupied_bandwidth(freqs, x, 3), C._occupied_bandwidth(freqs, x, 10),
+                            C._occupied_bandwidth(freqs, x, 20), C._spectral_flatness(x), C._spectral_kurtosis(x), float(thr),
+                            C._peak_spacing_std(freqs, pk)])
+            f = cpu_ref.row_features(freqs, x)
+        got = np.array([f["noise_floor_db"], f["snr_db"], f["bandwidth_hz_3db"], f["bandwidth_hz_10db"], f["bandwidth_hz_20db"],
+                        f["spectral_flatness"], f["spectral_kurtosis"], f["adaptive_threshold_db"], f["peak_spacing_std_hz"]])
+        assert np.array_equal(got, ref, equal_nan=True), (c, kind, n, got, ref)
+        assert np.array_equal(f["peak_idx"], np.array(pk, dtype=np.int64)), (c, kind, n)
+
+
 def test_freq_axis_equals_numpy_expression_for_random_lengths_and_rates():
     """streamer.py:120, `fftshift(fftfreq(N, 1/fs)) + fc`: the host axis equals numpy's expression bit for bit for
     odd and even lengths, powers of two up to 2^20, and arbitrary rates and centre frequencies."""
