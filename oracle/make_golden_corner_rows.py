@@ -69,6 +69,13 @@ def corner_rows():
     rows["very_negative_256"] = noise(256, 5.0, -400.0)                                   # all bins clipped to 1e-15 (:186)
     m = noise(1024, 5.0, -152.0)
     rows["straddles_the_clip_1024"] = m                                                   # some bins under -150 dB, some over
+    # (added after the rows above so that their random draws stay what they were)
+    pn = noise(4096); pn[[5, 1700, 4000]] = np.nan
+    rows["three_nans_in_4096"] = pn                                                       # np.percentile / np.max -> NaN: no peaks, 0 Hz
+    pn2 = noise(300); pn2[17] = np.nan
+    rows["one_nan_in_300"] = pn2
+    pn3 = noise(9000); pn3[8000] = np.nan
+    rows["one_nan_in_9000"] = pn3
     return rows
 
 

@@ -388,17 +388,28 @@ __device__ __forceinline__ void rf_finish(const RowFeatValues& r, int n, const R
         double* o = o_stats;
         o[0] = r.mx; o[1] = r.q0; o[2] = r.q1; o[3] = r.mean; o[4] = r.m2; o[5] = r.m4; o[6] = r.mean_lp; o[7] = r.mean_p;
         o[8] = r.f3; o[9] = r.l3; o[10] = r.f10; o[11] = r.l10; o[12] = r.f20; o[13] = r.l20; o[14] = r.amx; o[15] = n;
-        // numpy.percentile on a float32 row: a + (b-a)*gamma, or b - (b-a)*(1-gamma) when gamma >= 0.5, every
-        // operation rounded to float32 (no contraction); then classifier.py:46,55 with NEP-50 promotion:
-        // snr = float32(max - nf) widened; second = (max - float32(0.9*snr)) + 5 in float32; first = nf + 5 in
-        // float64; python max(first, second) compares second > float32(first).
-        const float diff = rf_sub_f32(r.q1, r.q0);
-        float nf = rf_add_f32(r.q0, rf_mul_f32(diff, prm.gamma));
-        if (prm.gamma >= 0.5f) nf = rf_sub_f32(r.q1, rf_mul_f32(diff, rf_sub_f32(1.0f, prm.gamma)));
-        const double snr = (double)rf_sub_f32(r.mx, nf);
-        const float second = rf_add_f32(rf_sub_f32(r.mx, (float)rf_mul_f64(0.9, snr)), 5.0f);
-        const double first = (double)nf + 5.0;
-        sh.thr = second > (float)first ? (double)second : first;
+        // A row that holds a NaN: np.max and np.percentile return NaN, `x >= NaN` selects no bin (0 Hz) and no peak
+        // passes a NaN threshold.  The scans above skip NaNs (maximum, order statistics of the finite values), so
+        // the reference's answer is put in place here.  The mean is NaN exactly when a NaN — or both infinities —
+        // went into the sum; a row whose maximum is +inf keeps its own results.
+        if (r.mean != r.mean && r.mx != INFINITY) {
+            const double nan = __builtin_nan("");
+            o[0] = nan; o[1] = nan; o[2] = nan;
+            o[8] = 0x7fffffff; o[9] = -1; o[10] = 0x7fffffff; o[11] = -1; o[12] = 0x7fffffff; o[13] = -1;
+            sh.thr = nan;
+        } else {
+            // numpy.percentile on a float32 row: a + (b-a)*gamma, or b - (b-a)*(1-gamma) when gamma >= 0.5, every
+            // operation rounded to float32 (no contraction); then classifier.py:46,55 with NEP-50 promotion:
+            // snr = float32(max - nf) widened; second = (max - float32(0.9*snr)) + 5 in float32; first = nf + 5 in
+            // float64; python max(first, second) compares second > float32(first).
+            const float diff = rf_sub_f32(r.q1, r.q0);
+            float nf = rf_add_f32(r.q0, rf_mul_f32(diff, prm.gamma));
+            if (prm.gamma >= 0.5f) nf = rf_sub_f32(r.q1, rf_mul_f32(diff, rf_sub_f32(1.0f, prm.gamma)));
+            const double snr = (double)rf_sub_f32(r.mx, nf);
+            const float second = rf_add_f32(rf_sub_f32(r.mx, (float)rf_mul_f64(0.9, snr)), 5.0f);
+            const double first = (double)nf + 5.0;
+            sh.thr = second > (float)first ? (double)second : first;
+        }
         if (o_thr) *o_thr = sh.thr;
         sh.pk[0] = -prm.min_distance;
         sh.pk[1] = 0;

@@ -259,7 +259,7 @@ def test_oracle_equals_reference_helpers_on_random_rows():
     finally:
         sys.path.remove(ref_root)
     rng = np.random.default_rng(400)
-    kinds = ["noise", "quantised", "tone", "steps", "wide", "holes", "const_tail", "ramp", "huge"]
+    kinds = ["noise", "quantised", "tone", "steps", "wide", "holes", "const_tail", "ramp", "huge", "nans"]
     for c in range(400):
         n = int(rng.choice([16, 64, 100, 257, 1000, 2048, 4096, 4097, 8192, 20000]))
         kind = kinds[c % len(kinds)]
@@ -280,6 +280,8 @@ def test_oracle_equals_reference_helpers_on_random_rows():
             x = np.linspace(-80, 5, n).astype(np.float32) + (rng.standard_normal(n) * 0.01).astype(np.float32)
         elif kind == "huge":
             x[rng.random(n) < 0.3] += np.float32(rng.uniform(400, 3000))
+        elif kind == "nans":
+            x[rng.integers(0, n, int(rng.integers(1, 4)))] = np.nan
         freqs = cpu_ref.freq_axis(n, 20e6, 2.4e9)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")

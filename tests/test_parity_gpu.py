@@ -964,8 +964,8 @@ def test_row_features_randomised(pkg):
     percentiles, -inf bins, plateaus, values past float32's 10^(x/10) range) through the per-row reductions, every
     exact quantity equal to the oracle's."""
     from tools import stress_features
-    done = stress_features.run(108, 5)
-    assert sum(done.values()) == 108 and min(done.values()) == 108 // len(stress_features.kinds)
+    done = stress_features.run(120, 5)
+    assert sum(done.values()) == 120 and min(done.values()) == 120 // len(stress_features.kinds)
 
 
 def test_waterfall_async_append_and_two_phase_gather(pkg):
