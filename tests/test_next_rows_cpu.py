@@ -299,6 +299,24 @@ def test_oracle_equals_reference_helpers_on_random_rows():
         assert np.array_equal(f["peak_idx"], np.array(pk, dtype=np.int64)), (c, kind, n)
 
 
+def test_oracle_welch_equals_mlab_psd_for_random_segmentations():
+    """scripts/process_sigmf_data.py:188-189 plots matplotlib's psd (mlab.psd, Hann, two-sided): the oracle's
+    welch_psd next to mlab.psd itself for random segment lengths (odd ones too), overlaps and rates, to 1e-12 of the
+    largest bin.  Skipped where matplotlib is absent; the committed ref_welch.npz is what travels."""
+    mlab = pytest.importorskip("matplotlib.mlab")
+    rng = np.random.default_rng(3)
+    for c in range(40):
+        n = int(rng.choice([16, 64, 100, 256, 1000, 1024, 4096]))
+        hop = int(rng.integers(1, n + 1))
+        segs = int(rng.integers(1, 30))
+        L = n + (segs - 1) * hop + int(rng.integers(0, hop))
+        fs = float(rng.choice([1e6, 2.4e6, 61.44e6]))
+        x = ((rng.standard_normal(L) + 1j * rng.standard_normal(L)) * rng.uniform(0.01, 100)).astype(np.complex64)
+        pxx, _ = mlab.psd(x, NFFT=n, Fs=fs, window=mlab.window_hanning, noverlap=n - hop)
+        got = cpu_ref.welch_psd(x, n, fs, hop=hop)
+        assert np.abs(got - pxx).max() <= 1e-12 * pxx.max(), (c, n, hop, segs)
+
+
 def test_freq_axis_equals_numpy_expression_for_random_lengths_and_rates():
     """streamer.py:120, `fftshift(fftfreq(N, 1/fs)) + fc`: the host axis equals numpy's expression bit for bit for
     odd and even lengths, powers of two up to 2^20, and arbitrary rates and centre frequencies."""
