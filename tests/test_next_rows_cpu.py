@@ -195,6 +195,45 @@ def test_streamer_shim_failure_behaviour_matches_reference_traces():
         assert _replay(sc) == sc["trace"], sc["name"]
 
 
+def test_streamer_shim_equals_reference_loop_on_random_failure_scripts():
+    """Where the reference is present (the build container): 300 random scripts — good frames, generic exceptions,
+    OSErrors of every errno class the loop distinguishes (9, 10054, 110, 113, others, none), frames the transform
+    rejects, reconnects that succeed on the k-th try or never, starting connected or not — through the reference's
+    own `_stream_data` (driven as oracle/make_golden_streamer.py drives it) and through SpectrumStreamer: the same
+    waits, reconnects and frames in the same order, and the same final state."""
+    import logging
+    import os
+    import sys
+    from unittest.mock import MagicMock
+    ref_root = os.environ.get("SDRK_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "app", "sdr")):
+        pytest.skip("the reference is not present on this machine")
+    from oracle import make_golden_streamer as G
+    sys.modules.setdefault("adi", MagicMock())
+    sys.path.insert(0, ref_root)
+    try:
+        import app.sdr.streamer as module
+    finally:
+        while ref_root in sys.path:
+            sys.path.remove(ref_root)
+    rng = np.random.default_rng(83)
+    steps = ["ok", {"raise": "Exception"}, {"raise": "ValueError"}, {"raise": "RuntimeError"}, {"raise": "OSError"},
+             {"raise": "OSError", "errno": 9}, {"raise": "OSError", "errno": 10054}, {"raise": "OSError", "errno": 110},
+             {"raise": "OSError", "errno": 113}, {"raise": "OSError", "errno": 5}, {"return": "garbage"}]
+    weights = np.array([6, 2, 1, 1, 1, 1, 1, 2, 1, 1, 1], dtype=float)
+    logging.disable(logging.CRITICAL)
+    try:
+        for c in range(300):
+            sc = {"name": f"random_{c}",
+                  "rx": [steps[i] for i in rng.choice(len(steps), size=int(rng.integers(1, 14)), p=weights / weights.sum())],
+                  "reconnect": [bool(b) for b in rng.random(int(rng.integers(0, 6))) < 0.4],
+                  "start_connected": bool(rng.random() < 0.85)}
+            want = G.run_scenario(module, module.SDRDataStreamer, sc)
+            assert _replay(sc) == want, sc
+    finally:
+        logging.disable(logging.NOTSET)
+
+
 def test_sigmf_source_cuts_and_loops(tmp_path):
     x = synth.synth_iq(8, 0, 3, 64).reshape(-1)
     sigmf_io.write_sigmf(str(tmp_path / "r"), x, 1e6, 0)
