@@ -76,6 +76,9 @@ def corner_rows():
     rows["one_nan_in_300"] = pn2
     pn3 = noise(9000); pn3[8000] = np.nan
     rows["one_nan_in_9000"] = pn3
+    for n in (1, 2, 3, 5):                                                                # shorter than one peak neighbourhood
+        rows[f"tiny_n{n}"] = noise(n)
+    rows["tiny_peak_n3"] = np.array([-80, -20, -80], dtype=np.float32)
     return rows
 
 

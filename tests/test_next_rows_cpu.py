@@ -261,8 +261,8 @@ def test_oracle_row_features_match_reference_classifier_helpers(golden):
 
 
 def test_oracle_row_features_match_reference_on_corner_rows(golden):
-    """The same restatement where realistic rows never go: 36 rows chosen for the corners of the device reductions
-    (lengths 16 ... 33000, ties, cliffs at the percentile, -inf bins, an all-NaN row, the all-zero frame's constant
+    """The same restatement where realistic rows never go: 41 rows chosen for the corners of the device reductions
+    (lengths 1 ... 33000, ties, cliffs at the percentile, -inf bins, an all-NaN row, the all-zero frame's constant
     row, overflowing and fully clipped flatness), against what the reference's helpers returned for them
     (oracle/make_golden_corner_rows.py).  Bit for bit, NaN where the reference gives NaN."""
     import warnings

@@ -700,8 +700,8 @@ def test_row_features_vs_reference_classifier_helpers(pkg, golden):
 
 
 def test_row_features_vs_reference_on_corner_rows(pkg, golden):
-    """f1 where realistic rows never go: the device reductions against what the REFERENCE's helpers returned for 36
-    corner rows (oracle/make_golden_corner_rows.py: lengths 16 ... 33000, more than 64 values tied at the percentile,
+    """f1 where realistic rows never go: the device reductions against what the REFERENCE's helpers returned for 41
+    corner rows (oracle/make_golden_corner_rows.py: lengths 1 ... 33000, more than 64 values tied at the percentile,
     cliffs, -inf bins, all-NaN, the constant -240.00002 dB row, combs at and just under the peak spacing, plateaus,
     maxima on the edge bins, flatness that overflows or is clipped entirely).  Exact where the reference is exact,
     NaN where it is NaN."""
