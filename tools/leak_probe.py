@@ -22,7 +22,22 @@ def plan(n, **kw):
     return f
 def wf():
     w = pkg.WaterfallBuffer(4096, maxlen=100); w.append(x[4096][0]); w.as_array(); w.close()
-kinds = {"plan4096": plan(4096, window="hann"), "plan1000": plan(1000), "plan8192": plan(8192), "plan65536": plan(65536, window="hann"),
+def wf_async():
+    with pkg.WaterfallBuffer(4096, maxlen=8, window="hann") as w:
+        d = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().sdrk_dev_alloc(0, x[4096].nbytes, ctypes.byref(d)))
+        _ffi.check(_ffi.lib().sdrk_memcpy_h2d(0, d, x[4096].ctypes.data_as(ctypes.c_void_p), x[4096].nbytes))
+        w.append_iq_device(d.value, 2, wait=False); w.gather_begin(None, decimate=16); w.gather_end(); w.sync()
+        _ffi.check(_ffi.lib().sdrk_dev_free(0, d))
+batch = r(1500, 4096)                                    # 48 MiB: the pipelined form of sdrk_frame_features_host
+def plan_batch():
+    with SpectrumPlan(4096, window="hann") as p:
+        p.spectrum_db(batch)
+def pinned():
+    a = pkg.pinned_empty((64, 4096), np.complex64); a[...] = 1; pkg.spectrum_db(a); del a
+kinds = {"waterfall_async": wf_async, "features_batch": lambda: features.frame_features(batch, 1e6, 2.4e9, max_peaks=16, as_arrays=True),
+         "host_pipeline": plan_batch, "pinned_arrays": pinned,
+         "plan4096": plan(4096, window="hann"), "plan1000": plan(1000), "plan8192": plan(8192), "plan65536": plan(65536, window="hann"),
          "fused": plan(65536, fused64k=True), "plan2^20": plan(1 << 20), "waterfall": wf,
          "features": lambda: features.frame_features(x[4096], 1e6, 2.4e9)}
 for name, f in kinds.items():
