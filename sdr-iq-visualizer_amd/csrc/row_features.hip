@@ -25,15 +25,19 @@ constexpr int RF_STAGE_MAX = 32768;   // bins: 128 KiB of the 160 KiB LDS
 // NCONST: the row length as a compile-time constant (4096, the reference's: bounds checks fold, 128 VGPRs without
 // spills) or 0 = the argument.
 template <bool STAGE, bool SHORT, int NCONST>
-__global__ __launch_bounds__(RF_THREADS, NCONST ? 4 : (SHORT ? 3 : 2)) void row_features_kernel(const float* __restrict__ rows, size_t n_rows, int nfft,
+__global__ __launch_bounds__(RF_THREADS, SHORT ? 4 : 2) void row_features_kernel(const float* __restrict__ rows, size_t n_rows, int nfft,
                                                                  RowFeatParams prm, double* __restrict__ stats,
                                                                  double* __restrict__ thr, int* __restrict__ idx,
                                                                  int* __restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) float rf_row[];
     __shared__ RowFeatShared sh;
-    const int tid = threadIdx.x;
     if (NCONST) nfft = NCONST;
     for (size_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        // (re-read per row behind an opaque copy: hoisted out of this persistent loop, the staging addresses derived
+        // from the thread number cost registers that the reductions then spill)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < RF_THREADS);
         const float* __restrict__ x = rows + r * (size_t)nfft;
         double* o_thr = thr ? thr + r : nullptr;
         int* o_idx = idx ? idx + r * (size_t)prm.max_peaks : nullptr;
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(RF_THREADS, NCONST ? 4 : (SHORT ? 3 : 2)) void row_
                 rf_v4f* __restrict__ l4 = reinterpret_cast<rf_v4f*>(rf_row);
                 for (int i = tid; i < nfft / 4; i += RF_THREADS) l4[i] = __builtin_nontemporal_load(&x4[i]);
             } else {
+#pragma unroll 1                                         // (a caller's oddly aligned rows: unrolled, its sixteen hoisted offsets spill)
                 for (int i = tid; i < nfft; i += RF_THREADS) rf_row[i] = x[i];
             }
             __syncthreads();

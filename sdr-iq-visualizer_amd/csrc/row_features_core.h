@@ -393,7 +393,7 @@ __device__ __forceinline__ void rf_finish(const RowFeatValues& r, int n, const R
         // the reference's answer is put in place here.  The mean is NaN exactly when a NaN — or both infinities —
         // went into the sum; a row whose maximum is +inf keeps its own results.
         if (r.mean != r.mean && r.mx != INFINITY) {
-            const double nan = __builtin_nan("");
+            const double nan = r.mean;                        // (it IS NaN here; a NaN constant gets hoisted and spilled)
             o[0] = nan; o[1] = nan; o[2] = nan;
             o[8] = 0x7fffffff; o[9] = -1; o[10] = 0x7fffffff; o[11] = -1; o[12] = 0x7fffffff; o[13] = -1;
             sh.thr = nan;
