@@ -22,8 +22,8 @@ constexpr int RF_STAGE_MAX = 32768;   // bins: 128 KiB of the 160 KiB LDS
 
 // SHORT rows (<= 4096 bins: the register-resident routine) are built for four workgroups per SIMD (<= 128 VGPRs, as
 // the fused kernel), longer rows (LDS / L2 scans, few registers needed, LDS-limited anyway) without a bound.
-// NCONST: the row length as a compile-time constant (4096, the reference's: bounds checks fold, 128 VGPRs without
-// spills) or 0 = the argument.
+// NCONST: the row length as a compile-time constant (4096, the reference's: bounds checks fold, 123 VGPRs and no
+// scratch) or 0 = the argument (128 VGPRs, four spilled registers).
 template <bool STAGE, bool SHORT, int NCONST>
 __global__ __launch_bounds__(RF_THREADS, SHORT ? 4 : 2) void row_features_kernel(const float* __restrict__ rows, size_t n_rows, int nfft,
                                                                  RowFeatParams prm, double* __restrict__ stats,
