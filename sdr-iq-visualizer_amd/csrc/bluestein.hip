@@ -76,13 +76,17 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_f
     using C = LdsCfg<LOG2M>;
     constexpr int M = C::N, P = C::P, R0 = C::R0, T = C::T, F = C::F, C0 = 16 / R0;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
-    const int tid = threadIdx.x;
-    const int fr = tid / T, tau = tid - fr * T;
-    float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
     LdsTw<LOG2M> tw;
-    lds_tw_init<LOG2M>(tw, twM, tau);
+    lds_tw_init<LOG2M>(tw, twM, (int)threadIdx.x % T);
     const size_t n_groups = (n_frames + F - 1) / F;
     for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        // (thread coordinates re-derived per group from an opaque copy of the thread number: hoisted out of this
+        // persistent loop, the sixteen sample offsets and their `n < N` masks cost the registers the transform spills)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < C::WG);
+        const int fr = tid / T, tau = tid - fr * T;
+        float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
         const size_t f = g * F + fr;
         const bool ok = f < n_frames;
         const float2* __restrict__ x = iq + (ok ? f : 0) * frame_stride;
@@ -122,15 +126,17 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_i
     using C = LdsCfg<LOG2M>;
     constexpr int M = C::N, P = C::P, R0 = C::R0, T = C::T, F = C::F, C0 = 16 / R0;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
-    const int tid = threadIdx.x;
-    const int fr = tid / T, tau = tid - fr * T;
-    float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
     LdsTw<LOG2M> tw;
-    lds_tw_init<LOG2M>(tw, twM, tau);
+    lds_tw_init<LOG2M>(tw, twM, (int)threadIdx.x % T);
     const size_t n_groups = (n_frames + F - 1) / F;
     const float inv_m = 1.0f / (float)M;
     const int rot = shift ? N / 2 : 0;
     for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        int tid = threadIdx.x;                                     // (as in blu_fwd_kernel)
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < C::WG);
+        const int fr = tid / T, tau = tid - fr * T;
+        float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
         const size_t f = g * F + fr;
         const bool ok = f < n_frames;
         const float2* __restrict__ x = work + (ok ? f : 0) * (size_t)M;
