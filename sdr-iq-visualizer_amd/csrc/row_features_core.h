@@ -551,7 +551,9 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     {   // histogram of the select: thread t owns bins 8t .. 8t+7 here and in the prefix scan
         typedef unsigned rf_v4u __attribute__((ext_vector_type(4)));
         rf_v4u* b4 = reinterpret_cast<rf_v4u*>(sh.bins);
-        const rf_v4u z = {0u, 0u, 0u, 0u};
+        unsigned zero = 0u;                                    // (made here: a constant zero vector gets hoisted out of the
+        asm volatile("" : "+v"(zero));                         //  caller's row loop into four registers and then spilled)
+        const rf_v4u z = {zero, zero, zero, zero};
         b4[2 * tid] = z;
         b4[2 * tid + 1] = z;
         if (tid == 0) sh.sel[3] = 0;
