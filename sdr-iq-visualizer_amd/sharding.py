@@ -194,6 +194,63 @@ def distributed_spectrum_db(samples=None, *, window=None, eps: float = 1e-12, sh
     return out
 
 
+def welch_piece(total_samples: int, nfft: int, hop: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """Which samples rank ``rank`` of ``world`` needs so that the ranks' segments are exactly the segments of the whole
+    stream: ``(first_sample, end_sample, n_segments)``.  The ``1 + (total - nfft) // hop`` segments are split into
+    contiguous ranges (``shard_ranges``); a rank's piece starts at its first segment and carries the ``nfft - hop``
+    samples of overlap its last segment needs ("an N−hop sample halo read, no exchange")."""
+    segs = 0 if total_samples < nfft else 1 + (total_samples - nfft) // hop
+    lo, hi = shard_ranges(segs, world)[rank]
+    if hi <= lo:
+        return 0, 0, 0
+    return lo * hop, (hi - 1) * hop + nfft, hi - lo
+
+
+def distributed_welch_psd(piece, nfft: int, sample_rate: float, *, hop: Optional[int] = None, window="hann",
+                          shift: bool = True, device: Optional[int] = None, group=None,
+                          compute: Optional[Callable[[np.ndarray], np.ndarray]] = None) -> np.ndarray:
+    """Averaged periodogram (``welch_psd``: scripts/process_sigmf_data.py:188-189) of one long recording whose samples
+    are spread over the ranks — the one place on this path with a real exchange step: every rank averages the
+    segments of its own piece on its GPU, then the per-rank sums and segment counts are **all-reduced** (RCCL when
+    the job's backend is nccl: ``nfft + 1`` float64 values, latency-bound) and every rank returns the same
+    ``(nfft,)`` float32 PSD.  ``piece`` is this rank's samples as ``welch_piece`` cuts them (a rank with no segment
+    passes an empty array).  ``compute(piece) -> (psd_of_piece float (nfft,), segments)`` replaces the per-rank
+    average — the CPU suite injects the oracle there to exercise the reduction under gloo."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised")
+    rank = dist.get_rank(group)
+    nfft = int(nfft)
+    hop = nfft if hop is None else int(hop)
+    if hop < 1:
+        raise ValueError("hop must be >= 1")
+    x = np.ascontiguousarray(np.asarray(piece).reshape(-1))
+    use_cuda = dist.get_backend(group) == "nccl"
+    if device is None and (compute is None or use_cuda):
+        device = _local_device(rank)
+    if compute is None:
+        from .spectrum import _cached_plan
+
+        def compute(p):
+            rows = 1 + (p.shape[0] - nfft) // hop
+            return _cached_plan(nfft, window, 1e-12, shift, device).welch_psd(p, sample_rate, hop), rows
+    acc = np.zeros(nfft + 1, dtype=np.float64)
+    if x.shape[0] >= nfft:
+        psd, rows = compute(x)
+        acc[:nfft] = np.asarray(psd, dtype=np.float64) * rows         # back to the sum over this rank's segments
+        acc[nfft] = rows
+    t = torch.from_numpy(acc)
+    if use_cuda:
+        t = t.to(torch.device("cuda", int(device)))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    total = t.cpu().numpy()
+    if total[nfft] < 1:
+        raise ValueError("no rank holds a full segment")
+    return (total[:nfft] / total[nfft]).astype(np.float32)
+
+
 _host_groups: dict = {}
 
 

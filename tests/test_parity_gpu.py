@@ -1454,6 +1454,41 @@ def test_one_process_per_gpu_path_under_torchrun(pkg, tmp_path):
     assert r.returncode == 0 and "rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_welch_over_ranks_rccl_all_reduce_under_torchrun(pkg, tmp_path):
+    """sharding.distributed_welch_psd with the product transform under torch.distributed, backend "nccl" (= RCCL), one
+    rank per visible GPU (up to 4; one rank on a 1-GPU box — the segment arithmetic for more ranks is covered by the
+    gloo tests): each rank averages the segments of its own piece on its GPU, the sums are all-reduced as a device
+    tensor, every rank ends with the PSD of the whole recording."""
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    script = tmp_path / "welch_rank.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "import numpy as np\n"
+        "from oracle import cpu_ref\n"
+        "from sdr_iq_visualizer_amd import sharding\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', int(os.environ['LOCAL_RANK'])))\n"
+        "rng = np.random.default_rng(12)\n"
+        "total, nfft, hop, fs = 300000, 1024, 512, 2.4e6\n"
+        "x = ((rng.standard_normal(total) + 1j * rng.standard_normal(total)) * 5).astype(np.complex64)\n"
+        "a, b, segs = sharding.welch_piece(total, nfft, hop, dist.get_rank(), dist.get_world_size())\n"
+        "out = sharding.distributed_welch_psd(x[a:b], nfft, fs, hop=hop)\n"
+        "ref = cpu_ref.welch_psd(x, nfft, fs, hop=hop)\n"
+        "err = float(np.abs(out - ref).max() / ref.max())\n"
+        "assert out.shape == (nfft,) and out.dtype == np.float32 and err <= 1e-5, err\n"
+        "if dist.get_rank() == 0:\n"
+        "    print('welch ok', err, segs)\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    nproc = max(1, min(pkg.device_count(), 4))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                        "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "welch ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("cus", [4, 40, 96])
 def test_persistent_grids_smaller_than_the_device(pkg, monkeypatch, cus):
     """Plans size their persistent grids from the CU count; on a partition of the device (or with SDRK_NUM_CUS)
