@@ -56,6 +56,8 @@ def parse_args():
                     help="budget for the single-core numpy cpu_baseline leg (0 disables both CPU legs)")
     ap.add_argument("--cpu-all-cores-seconds", type=float, default=5.0,
                     help="budget for the all-cores leg (0 disables it; pure CPU, forked before any GPU runtime loads)")
+    ap.add_argument("--cpu-large-seconds", type=float, default=2.5,
+                    help="budget of EACH of the four CPU legs beside configs 3 and 5 (one core / all cores; 0 disables)")
     ap.add_argument("--parity-frames", type=int, default=1024,
                     help="random frames of the timed output checked against the oracle (SURVEY.md §8d: >= 1024)")
     ap.add_argument("--placement-candidates", type=int, default=6,
@@ -153,6 +155,62 @@ def cpu_baseline_all_cores(window: str, seconds: float):
     return {"value": round(total, 1), "unit": "Msamples/s", "cores": workers,
             "visible_cpus": affinity, "cgroup_cpu_quota": None if quota is None else round(quota, 1),
             "sample": f"one forked oracle worker per usable CPU for {seconds:.0f} s each, same generator and window"}
+
+
+def _large_frame_loop(job):
+    """The oracle on one large-frame configuration for `seconds` (one core; also the all-cores worker): the stream is
+    made of the same generator frames the device legs use (seed 99), `rows` frames of `nfft` at spacing `hop`;
+    hop < nfft goes through cpu_ref.stft_db (row r = spectrum_db(iq[r*hop : r*hop + nfft]), the reference
+    expression of streamer.py:119-121 per row), packed frames through cpu_ref.spectrum_db one frame at a time."""
+    import numpy as np
+    from oracle import cpu_ref
+    from sdr_iq_visualizer_amd import synth
+    seed, nfft, hop, rows, window, seconds = job
+    in_samples = (rows - 1) * hop + nfft
+    iq = synth.synth_iq(seed, 0, (in_samples + 4095) // 4096, 4096).reshape(-1)[:in_samples]
+    w = np.hanning(nfft).astype(np.float32) if window == "hann" else None
+    cpu_ref.spectrum_db(iq[:nfft], window=w)                                  # warm-up (pocketfft plan, pages)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        if hop < nfft:
+            cpu_ref.stft_db(iq, nfft, hop, window=w)
+        else:
+            for r in range(rows):
+                cpu_ref.spectrum_db(iq[r * hop: r * hop + nfft], window=w)
+        done += rows
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            return done, dt
+
+
+def cpu_baseline_large(nfft, hop, rows, window, seconds, all_cores_seconds):
+    """BASELINE.md §3 item 4 / SURVEY.md §8(d) "CPU baseline": the reference expression timed at the large-frame
+    configurations in the same run — one core, then one forked worker per usable CPU (pure numpy, before any GPU
+    runtime is up).  Rates in frame-samples/s (rows*N per second, the unit of `frame_Msamples_per_s` beside it)."""
+    import numpy as np
+    done, dt = _large_frame_loop((99, nfft, hop, rows, window, seconds))
+    out = {"value": round(done * nfft / dt / 1e6, 2), "unit": "Msamples/s (frame-samples: rows*N per second)",
+           "cores": 1, "kind": "port",
+           "input_stream_Msamples_per_s": round(done * hop / dt / 1e6, 2),
+           "sample": f"{done} rows of N={nfft} at hop {hop} ({window}) in {dt:.1f} s: oracle/cpu_ref."
+                     + ("stft_db" if hop < nfft else "spectrum_db per frame")
+                     + f" over a {rows}-row stream, numpy {np.__version__}"}
+    if all_cores_seconds > 0:
+        import multiprocessing as mp
+        workers, affinity, quota = usable_cpus()
+        with mp.get_context("fork").Pool(workers) as pool:
+            res = pool.map(_large_frame_loop, [(99 + i, nfft, hop, rows, window, all_cores_seconds) for i in range(workers)])
+        total = sum(r[0] for r in res) * nfft / max(r[1] for r in res) / 1e6
+        out["all_cores"] = {"value": round(total, 1), "unit": "Msamples/s (frame-samples)", "cores": workers,
+                            "visible_cpus": affinity, "cgroup_cpu_quota": None if quota is None else round(quota, 1),
+                            "sample": f"one forked oracle worker per usable CPU for {all_cores_seconds:.0f} s each, own stream per worker"}
+    return out
+
+
+def cpu_baselines_secondary(seconds=2.5, all_cores_seconds=2.5):
+    """The host numbers that stand beside secondary.config3 / config5 (about 4 x 2.5 s in all)."""
+    return {"config3": cpu_baseline_large(65536, 32768, 64, "hann", seconds, all_cores_seconds),
+            "config5": cpu_baseline_large(1 << 20, 1 << 20, 4, "hann", seconds, all_cores_seconds)}
 
 
 # ---- clock / power telemetry -----------------------------------------------------------------
@@ -360,8 +418,11 @@ def numpy_boundary(lib, _ffi, pkg, synth, dev):
     out = {"what": "pkg.spectrum_db(complex64 numpy (B,4096)) -> float32 numpy, pageable arrays, N=4096 rect",
            "link_probe_GBps": {"h2d": round(a.value, 1), "d2h": round(b.value, 1), "duplex_upstream": round(c.value, 1)},
            "host_helper_threads": int(lib.sdrk_host_threads()), "by_batch": {}}
-    for bsz in (1, 16, 256, 4096, 32768):
-        x = synth.synth_iq(1, 0, bsz, NFFT)
+    for bsz in (1, 16, 256, 4096, 32768, 65536):
+        if bsz <= 32768:
+            x = synth.synth_iq(1, 0, bsz, NFFT)
+        else:                                                   # SURVEY.md 8(d)'s largest batch: the 32768 frames twice
+            x = np.concatenate([x, x])                          # (the generator in numpy would take longer than the leg)
         one = x[0] if bsz == 1 else x
         pkg.spectrum_db(one, device=dev)                        # plan + staging warm-up
         reps = 300 if bsz <= 16 else (9 if bsz <= 4096 else 3)
@@ -509,6 +570,46 @@ def feature_reductions(lib, _ffi, SpectrumPlan, features, dev, n_frames=1 << 18)
             lib.sdrk_dev_free(dev, b)
 
 
+def negotiate_backend(dist, world, rank, gloo_group, stages):
+    """The nccl-or-gloo choice as a COLLECTIVE decision (every rank calls this with the same number of stages).
+    Each stage is a callable that raises on failure; after each stage the ranks vote over gloo (which is already up).
+    All ranks fine after the last stage -> ("nccl", whatever the last stage returned, None).  No rank fine at some
+    stage -> ("gloo", gloo_group, note): the data path has no collective, so the barrier and the reductions of the
+    times can run over gloo and the line says so.  Some fine, some not -> every rank exits non-zero with the reason:
+    no rank is ever left inside an nccl collective that others have abandoned."""
+    import torch
+    result = None
+    for i, stage in enumerate(stages):
+        try:
+            result, err = stage(), None
+        except Exception as e:                                   # noqa: BLE001 - voted on below
+            result, err = None, f"{type(e).__name__}: {str(e)[:160]}"
+        votes = torch.tensor([0 if err else 1, 1 if err else 0], dtype=torch.int64)
+        dist.all_reduce(votes, group=gloo_group)
+        n_ok, n_bad = int(votes[0]), int(votes[1])
+        if n_bad == 0:
+            continue
+        reasons = [None] * world
+        dist.all_gather_object(reasons, err, group=gloo_group)
+        bad = [r for r, why in enumerate(reasons) if why]
+        first = reasons[bad[0]]
+        if n_ok == 0:
+            return "gloo", gloo_group, f"nccl did not come up on any rank (stage {i}: {first}); barrier and reductions on gloo"
+        raise SystemExit(f"[bench] rank {rank}: nccl came up on {n_ok} of {world} ranks only (stage {i}, failed on ranks "
+                         f"{bad}: {first}); no consistent rendezvous backend, every rank gives up")
+    return "nccl", result, None
+
+
+def _injected_nccl_failure(rank):
+    """Rehearsal hook (tools / tests only): SDRK_BENCH_FAIL_NCCL=all (or 1) fails every rank, =rank:K only rank K."""
+    spec = os.environ.get("SDRK_BENCH_FAIL_NCCL")
+    if not spec:
+        return False
+    if spec.startswith("rank:"):
+        return rank == int(spec.split(":", 1)[1])
+    return True
+
+
 def child_command(args, port):
     """The one-rank-per-GPU launch of this file (what the driver itself runs for N > 1)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -579,6 +680,9 @@ def main():
         cpu = cpu_baseline(args.window, args.cpu_seconds if solo else min(args.cpu_seconds, 5.0))
         if solo and args.cpu_all_cores_seconds > 0:
             cpu["all_cores"] = cpu_baseline_all_cores(args.window, args.cpu_all_cores_seconds)
+    cpu_large = None
+    if solo and not args.no_secondary and args.cpu_seconds > 0 and args.cpu_large_seconds > 0:
+        cpu_large = cpu_baselines_secondary(args.cpu_large_seconds, args.cpu_large_seconds)
 
     import torch  # before libsdrk: one shared HIP runtime in the process (see _ffi.py)
     import numpy as np
@@ -595,33 +699,37 @@ def main():
     backend = "nccl" if n_dev >= world else "gloo"
     if n_dev < world:
         args.placement_candidates = 1               # ranks share a GPU here: no probing with its memory
-    backend_note = None
+    backend_note, grp = None, None
     if "RANK" in os.environ:
+        import datetime
         import torch.distributed as dist
         torch.cuda.set_device(dev)
+        # gloo first: it always comes up, carries the votes below, and is the fallback for the barrier and the
+        # reductions of the times (the data path itself has no collective)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+        grp = dist.group.WORLD
         if backend == "nccl":
-            # the communicator is formed (and proven: one all-reduce) here, before the warm-up.  The data path has no
-            # collective, so a node whose RCCL does not come up can still be measured: if every rank fails the same
-            # way the barrier and the reductions of the times move to gloo, and the line says so.
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-                if os.environ.get("SDRK_BENCH_FAIL_NCCL"):           # rehearsal of the fallback below (tools only)
+            state = {}
+
+            def willing():                          # local preconditions, voted on BEFORE anybody enters new_group
+                if _injected_nccl_failure(rank):    # (which ends in a barrier over all ranks)
                     raise RuntimeError("SDRK_BENCH_FAIL_NCCL is set")
+                if not torch.cuda.is_available():
+                    raise RuntimeError("no GPU visible to this rank")
+
+            def form():
+                state["g"] = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+                return state["g"]
+
+            def prove():                            # the communicator is formed and proven here, before the warm-up
                 probe = torch.ones(1, device="cuda")
-                dist.all_reduce(probe)
+                dist.all_reduce(probe, group=state["g"])
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     raise RuntimeError(f"all-reduce of ones over {world} ranks gave {probe.item()}")
-            except Exception as e:                                   # noqa: BLE001 - reported in the line
-                backend_note = f"nccl did not come up ({type(e).__name__}: {str(e)[:160]}); barrier and reductions on gloo"
-                try:
-                    dist.destroy_process_group()
-                except Exception:                                    # noqa: BLE001
-                    pass
-                backend = "gloo"
-                dist.init_process_group("gloo")          # same store (under torchrun it is the agent's): keys do not clash
-        else:
-            dist.init_process_group("gloo")
+                return state["g"]
+
+            backend, grp, backend_note = negotiate_backend(dist, world, rank, dist.group.WORLD, [willing, form, prove])
     red_dev = "cuda" if backend == "nccl" else "cpu"
     lib = _ffi.lib()
     _ffi.require_device(dev)
@@ -650,7 +758,7 @@ def main():
         plan.sync()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=grp, **({"device_ids": [dev]} if backend == "nccl" else {}))
 
     for _ in range(args.warmup):
         plan.exec_device(d_in.value, frames, d_out.value)
@@ -672,11 +780,11 @@ def main():
         # every rank's own median launch and wall time, so that a straggler (placement level, clocks) shows in the line
         mine = torch.tensor([_median(list(each_ms)), elapsed * 1e3 / args.steps], device=red_dev, dtype=torch.float64)
         everyone = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(everyone, mine)
+        dist.all_gather(everyone, mine, group=grp)
         per_rank = {"launch_ms_median": [round(float(v[0]), 4) for v in everyone],
                     "wall_ms_per_step": [round(float(v[1]), 4) for v in everyone]}
         t = torch.tensor([elapsed, kernel_ms], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
     # parity on this rank's output of the timed launches (oracle = checker only)
@@ -695,7 +803,7 @@ def main():
         n_checked = int(picks.size)
     if dist is not None:
         t = torch.tensor([parity], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
         parity = float(t[0])
 
     # the same bytes with no arithmetic, same buffers, same process: the measured-copy ceiling (rank 0)
@@ -752,11 +860,21 @@ def main():
             r["realtime_factor_at_61.44_Msps"] = round(10.0 / (r["ms"] * 1e-3), 1)
             r["workload"] = "BASELINE.json configs[2]: waterfall STFT N=65536, 50 % overlap, 10 s @ 61.44 Msps"
             r["kernels"] = "sdrk::col_pass_kernel<8,..> + sdrk::row_pass_kernel<8,0> per 384-frame chunk (192 MiB scratch)"
+            if cpu_large:
+                r["cpu_baseline"] = cpu_large["config3"]
+                r["gpu_over_one_core"] = round(r["frame_Msamples_per_s"] / cpu_large["config3"]["value"], 1)
             secondary["config3"] = r
             r = device_config(lib, _ffi, SpectrumPlan, dev, 1 << 20, 256, 1 << 20, "hann", 7)
             r["workload"] = "BASELINE.json configs[4], one channel: 256 back-to-back N=2^20 frames"
             r["realtime_factor_at_61.44_Msps"] = round((256 * (1 << 20) / 61.44e6) / (r["ms"] * 1e-3), 1)
+            if cpu_large:
+                r["cpu_baseline"] = cpu_large["config5"]
+                r["gpu_over_one_core"] = round(r["frame_Msamples_per_s"] / cpu_large["config5"]["value"], 1)
             secondary["config5_one_channel"] = r
+            r = device_config(lib, _ffi, SpectrumPlan, dev, 1 << 20, 256, 1 << 20, None, 7, scratch_candidates=3)
+            r["workload"] = "BASELINE.json configs[4], one channel, rectangular window (SURVEY.md 8d: rect and Hann)"
+            r["realtime_factor_at_61.44_Msps"] = round((256 * (1 << 20) / 61.44e6) / (r["ms"] * 1e-3), 1)
+            secondary["config5_one_channel_rect"] = r
             secondary["config5_channel_with_ring_and_gather"] = channel_config5(lib, _ffi, pkg, SpectrumPlan, dev)
             secondary["numpy_boundary"] = numpy_boundary(lib, _ffi, pkg, synth, dev)
             from sdr_iq_visualizer_amd import features
@@ -843,7 +961,7 @@ def main():
             line["secondary"] = secondary
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier()                               # the default (gloo) group: every rank is done with its GPU
         dist.destroy_process_group()
 
 

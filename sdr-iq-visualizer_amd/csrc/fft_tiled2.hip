@@ -18,6 +18,22 @@
 // 256 MiB Infinity Cache between the pass that writes them and the pass that reads them.
 #include "fft_lds_core.h"
 
+// cache-policy bits of the four streams (buffer `aux` operand on gfx950: 1 = sc0, 2 = nt, 16 = sc1).  The defaults are
+// what ships; the macros exist for A/B builds (tools/variant.sh) — round 4 measured every combination that names a
+// different path through the L2 / Infinity Cache for the scratch.
+#ifndef SDRK_COL_LD_AUX
+#define SDRK_COL_LD_AUX 2    // input samples: read once
+#endif
+#ifndef SDRK_SCR_ST_AUX
+#define SDRK_SCR_ST_AUX 0    // scratch written by the col pass ...
+#endif
+#ifndef SDRK_SCR_LD_AUX
+#define SDRK_SCR_LD_AUX 0    // ... and read back by the row pass of the same chunk
+#endif
+#ifndef SDRK_ROW_ST_AUX
+#define SDRK_ROW_ST_AUX 2    // dB rows: written once
+#endif
+
 namespace sdrk {
 
 // (scratch_index, the layout of the intermediate between the passes, lives in fft_lds_core.h)
@@ -90,7 +106,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
         const int e0 = tau * M + m;          // element (n3 = tau, m)
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-            x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, 2));
+            x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, SDRK_COL_LD_AUX));
     };
     auto store = [&](size_t f, int m, const cf (&v)[16], const cf (&bw)[16]) {
         const __amdgpu_buffer_rsrc_t ro = frame_rsrc(scratch + f * nfft, (unsigned)(nfft * 8));
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
             const cf z = cmul(v[rev16(q)], bw[q]);
             const v2f sv = {z.x, z.y};
             const int u = scratch_index(T * q, 0, M);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, u * 8, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, u * 8, SDRK_SCR_ST_AUX);
         }
     };
 
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
             const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + (live ? f : f_begin) * frame_stride, live ? (unsigned)(nfft * 8) : 0u);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (q >= q0) x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, 2));
+                if (q >= q0) x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, SDRK_COL_LD_AUX));
         };
         v2f xa[16], xb[16];
         issue_from(f_begin, xa, 0);
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kerne
             for (int q = 0; q < 16; ++q) {
                 const cf z = cmul(v[rev16(q)], bw[q]);
                 const v2f sv = {z.x, z.y};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, scratch_index(T * q, 0, M) * 8, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, scratch_index(T * q, 0, M) * 8, SDRK_SCR_ST_AUX);
             }
         }
     }
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 51
         for (int i = 0; i < C0; ++i)
 #pragma unroll
             for (int j = 0; j < R0; ++j) {
-                const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, 0));
+                const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, SDRK_SCR_LD_AUX));
                 v[i * R0 + j] = cf{x.x, x.y};
             }
         lds_fft_core<LOG2M, 1>(v, lds, 0, rt, tw);
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 51
             for (int i = 0; i < 16; ++i) {
                 const float val = tile[(km0 + T * i) * (ROWS + 1) + r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, (km0 * A + r) * 4,
-                                                      i * T * A * 4, 2);
+                                                      i * T * A * 4, SDRK_ROW_ST_AUX);
             }
         } else {
             float2* __restrict__ tile = lds_all;  // [km][ROWS + 1]
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
             for (int i = 0; i < C0; ++i)
 #pragma unroll
                 for (int j = 0; j < R0; ++j) {
-                    const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, 0));
+                    const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, SDRK_SCR_LD_AUX));
                     v[i * R0 + j] = cf{x.x, x.y};
                 }
             lds_fft_core<LOG2M, 1>(v, lds, 0, rt, tw);
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
 #pragma unroll 8
             for (int i = 0; i < 16 * M / WGT; ++i) {
                 const float x = tile[(km0 + (WGT / 16) * i) * 17 + r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), ro, (km0 * A + r) * 4, i * (WGT / 16) * A * 4, 2);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), ro, (km0 * A + r) * 4, i * (WGT / 16) * A * 4, SDRK_ROW_ST_AUX);
             }
             __syncthreads();  // tile reads done before the next band's exchanges
         }
