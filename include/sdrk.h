@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SDRK_VERSION 200 /* 0.2.0 */
+#define SDRK_VERSION 400 /* 0.4.0: every addition to this ABI bumps it; _ffi.py refuses a library of another version */
 
 typedef enum sdrk_status {
     SDRK_OK = 0,
@@ -275,6 +275,37 @@ int sdrk_frame_features_host(sdrk_plan* plan, const void* iq_c64, size_t n_frame
                              size_t frame_stride, int rank, float gamma, int min_distance,
                              int max_peaks, double* out_stats, double* out_thr, int32_t* out_idx,
                              int32_t* out_count, float* out_db);
+
+/* The same measurements FINISHED on the device, for a whole batch: what classify_signal_advanced forms from its helpers'
+ * results before the rule ladder (classifier.py:45-58) as planes of n_rows 8-byte words — the host receives arrays, not
+ * packed per-row records that it then has to post-process row by row.  out_planes: SDRK_FEAT_PLANES * n_rows words;
+ * plane P, row r at out_planes[P * n_rows + r]:
+ *   double planes   SDRK_FEAT_MAX_DB                np.max(power_db)                                    (:46)
+ *                   SDRK_FEAT_NOISE_FLOOR_DB        np.percentile(power_db, q) as numpy forms it on a float32 row (:179-181)
+ *                   SDRK_FEAT_SNR_DB                float32(max - noise floor)                          (:46)
+ *                   SDRK_FEAT_FLATNESS              clip(exp(mean ln p) / mean p, 0, 1)                 (:183-189)
+ *                   SDRK_FEAT_KURTOSIS              0 if sigma < 1e-9 else m4 / m2^2                    (:191-198)
+ *                   SDRK_FEAT_THRESHOLD_DB          the adaptive peak threshold                         (:55)
+ *                   SDRK_FEAT_PEAK_SPACING_STD_HZ   np.std(np.diff(freqs[peaks])) over the kept peaks, 0 for < 3 (:214-219)
+ *                   SDRK_FEAT_PEAK_DENSITY          peak_count / nfft                                   (:58)
+ *                   SDRK_FEAT_BANDWIDTH_HZ + j      freqs[last] - freqs[first] of the bins within 3 / 10 / 20 dB (j = 0, 1, 2)
+ *                                                   of the maximum, 0.0 when no bin qualifies           (:163-170)
+ *   int64 planes    SDRK_FEAT_ARGMAX, SDRK_FEAT_PEAK_COUNT (total found; may exceed max_peaks)
+ *                   SDRK_FEAT_OCCUPIED_BINS + 2 j   the (first, last) bin pairs behind bandwidth j: 2 * n_rows words,
+ *                                                   row r at [2 r], [2 r + 1]
+ * freqs: the nfft float64 bin frequencies (streamer.py:120), host memory; NULL: the three Hz quantities are 0.
+ * out_idx (n_rows * max_peaks int32, unused slots -1) may be NULL: then no peaks are looked for (count 0). */
+enum {
+    SDRK_FEAT_MAX_DB = 0, SDRK_FEAT_NOISE_FLOOR_DB, SDRK_FEAT_SNR_DB, SDRK_FEAT_FLATNESS, SDRK_FEAT_KURTOSIS,
+    SDRK_FEAT_THRESHOLD_DB, SDRK_FEAT_PEAK_SPACING_STD_HZ, SDRK_FEAT_PEAK_DENSITY, SDRK_FEAT_BANDWIDTH_HZ /* 3 planes */,
+    SDRK_FEAT_ARGMAX = 11, SDRK_FEAT_PEAK_COUNT, SDRK_FEAT_OCCUPIED_BINS /* 6 planes */, SDRK_FEAT_PLANES = 19
+};
+int sdrk_row_features_planes(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft,
+                             int rank, float gamma, int min_distance, int max_peaks, const double* freqs,
+                             void* out_planes, int32_t* out_idx);
+int sdrk_frame_features_host_planes(sdrk_plan* plan, const void* iq_c64, size_t n_frames, size_t frame_stride,
+                                    int rank, float gamma, int min_distance, int max_peaks, const double* freqs,
+                                    void* out_planes, int32_t* out_idx, float* out_db);
 
 /* ---- waterfall ring -------------------------------------------------------
  * Replaces deque(maxlen=100) / append / np.array(deque) at

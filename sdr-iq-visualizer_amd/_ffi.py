@@ -30,6 +30,11 @@ WINDOW_HANN = 1
 WINDOW_CUSTOM = 2
 
 MAX_LOG2_NFFT = 22
+ABI_VERSION = 400                 # SDRK_VERSION of include/sdrk.h this binding was written against
+FEAT_PLANES = 19                  # SDRK_FEAT_* plane numbers of include/sdrk.h
+(FEAT_MAX_DB, FEAT_NOISE_FLOOR_DB, FEAT_SNR_DB, FEAT_FLATNESS, FEAT_KURTOSIS, FEAT_THRESHOLD_DB, FEAT_PEAK_SPACING_STD_HZ,
+ FEAT_PEAK_DENSITY, FEAT_BANDWIDTH_HZ) = range(9)
+FEAT_ARGMAX, FEAT_PEAK_COUNT, FEAT_OCCUPIED_BINS = 11, 12, 13
 PLAN_FUSED64K = 0x1
 PLAN_OVERLAP_PASSES = 0x2
 
@@ -94,6 +99,10 @@ SYMBOLS = [
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("sdrk_frame_features_host", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_float, c_int, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("sdrk_row_features_planes", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_int, c_float, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p]),
+    ("sdrk_frame_features_host_planes", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_float, c_int, c_int,
+                                                c_void_p, c_void_p, c_void_p, c_void_p]),
     ("sdrk_row_stats", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p]),
     ("sdrk_row_peaks", c_int, [c_int, c_void_p, c_int, c_size_t, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("sdrk_waterfall_create", c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
@@ -134,6 +143,11 @@ def lib() -> ctypes.CDLL:
                 "There is no CPU fallback for the spectrum path."
             )
         handle = ctypes.CDLL(_LIB_PATH)
+        handle.sdrk_version.restype = c_int
+        built = int(handle.sdrk_version())
+        if built != ABI_VERSION:         # a stale build: say so, instead of an AttributeError on some newer symbol
+            raise ImportError(f"{_LIB_PATH} reports ABI version {built}, this package expects {ABI_VERSION}: rebuild it "
+                              f"with `make -C {os.path.join(_PKG_DIR, 'csrc')}`")
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(handle, name)  # AttributeError if the build lacks a symbol
             fn.restype = restype

@@ -101,6 +101,10 @@ hipError_t launch_blu_post(const void* d_Y, const void* d_chirp, size_t n_frames
 hipError_t launch_row_features(const float* d_rows, size_t n_rows, int nfft, int rank, float gamma, int min_distance,
                                int max_peaks, double* d_stats, double* d_thr, int* d_idx, int* d_cnt, int num_cus,
                                hipStream_t s);
+// the per-row arithmetic behind the scans, for a batch of packed results -> SDRK_FEAT_* planes (row_features.hip)
+hipError_t launch_feature_finalize(const double* d_stats, const double* d_thr, const int* d_idx, const int* d_cnt,
+                                   size_t n_rows, int nfft, float gamma, int max_peaks, const double* d_freqs,
+                                   double* d_out, hipStream_t s);
 // the N = 4096 transform with those measurements as its epilogue (fft4096_features.hip); a.d_out may be null
 hipError_t launch_fft4096_features(const LaunchArgs& a, int rank, float gamma, int min_distance, int max_peaks,
                                    double* d_stats, double* d_thr, int* d_idx, int* d_cnt);

@@ -15,6 +15,7 @@
 // row_peaks_kernel            the peak scan alone, for caller-supplied thresholds (sdrk_row_peaks).
 // The N = 4096 transform can also run the same routine as its epilogue (fft4096.hip, EPI_FEATURES).
 #include "row_features_core.h"
+#include "../../include/sdrk.h"   // SDRK_FEAT_* plane numbers
 
 namespace sdrk {
 
@@ -102,6 +103,84 @@ __global__ __launch_bounds__(RF_THREADS) void row_peaks_kernel(const float* __re
         __syncthreads();
     }
     if (tid == 0) out_count[blockIdx.x] = sh_state[1];
+}
+
+// The per-row arithmetic the reference does AFTER its helpers' scans, for a whole batch at once (round 4): what
+// features._assemble_arrays used to do in numpy over the packed results (12-14 ms per 32768 frames, 40 % of the host
+// call) now happens here, one wave per row, and the host receives finished planes (sdrk.h: SDRK_FEAT_*):
+//   noise floor  = numpy.percentile's float32 interpolation between sorted[rank], sorted[rank+1]  (classifier.py:179-181)
+//   snr          = float32(max - noise floor)                                                      (:46)
+//   flatness     = clip(exp(mean ln p) / mean p, 0, 1)                                             (:186-189)
+//   kurtosis     = 0 if sigma < 1e-9 else m4 / m2^2                                                (:195-198)
+//   bandwidths   = f[last] - f[first] of the bins within 3 / 10 / 20 dB of the maximum, 0 when there is none (:163-170)
+//   peak spacing = std(diff(f[peaks])) over the kept peaks, 0 for fewer than three                  (:214-219)
+//   peak density = peak_count / nfft
+// Every float32 step is written with the rf_*_f32 helpers (no contraction), as in rf_finish.
+__global__ __launch_bounds__(256) void feature_finalize_kernel(const double* __restrict__ stats, const double* __restrict__ thr,
+                                                               const int* __restrict__ idx, const int* __restrict__ cnt,
+                                                               size_t n_rows, int nfft, float gamma, int max_peaks,
+                                                               const double* __restrict__ freqs, double* __restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= n_rows) return;
+    const double* __restrict__ s = stats + r * 16;
+    long long* __restrict__ outi = reinterpret_cast<long long*>(out);
+    const int k_all = cnt ? cnt[r] : 0;
+    const int k = k_all < max_peaks ? k_all : max_peaks;
+    // peak spacing: two passes over the <= max_peaks kept indices, lanes striding the slots, float64 wave sums
+    double spacing = 0.0;
+    if (freqs && idx && k >= 3) {
+        const int* __restrict__ pk = idx + r * (size_t)max_peaks;
+        const int m = k - 1;
+        double acc = 0.0;
+        for (int j = lane; j < m; j += 64) acc += freqs[pk[j + 1]] - freqs[pk[j]];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        const double mean = acc / m;
+        double v = 0.0;
+        for (int j = lane; j < m; j += 64) {
+            const double d = (freqs[pk[j + 1]] - freqs[pk[j]]) - mean;
+            v += d * d;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        spacing = sqrt(v / m);
+    }
+    if (lane != 0) return;
+    const float mx = (float)s[0], q0 = (float)s[1], q1 = (float)s[2];
+    const float diff = rf_sub_f32(q1, q0);
+    float nf = rf_add_f32(q0, rf_mul_f32(diff, gamma));
+    if (gamma >= 0.5f) nf = rf_sub_f32(q1, rf_mul_f32(diff, rf_sub_f32(1.0f, gamma)));
+    out[SDRK_FEAT_MAX_DB * n_rows + r] = (double)mx;
+    out[SDRK_FEAT_NOISE_FLOOR_DB * n_rows + r] = (double)nf;
+    out[SDRK_FEAT_SNR_DB * n_rows + r] = (double)rf_sub_f32(mx, nf);
+    double fl = exp(s[6]) / s[7];
+    fl = fl < 0.0 ? 0.0 : (fl > 1.0 ? 1.0 : fl);                                   // (NaN stays NaN, as np.clip leaves it)
+    out[SDRK_FEAT_FLATNESS * n_rows + r] = fl;
+    out[SDRK_FEAT_KURTOSIS * n_rows + r] = sqrt(s[4]) < 1e-9 ? 0.0 : s[5] / (s[4] * s[4]);
+    out[SDRK_FEAT_THRESHOLD_DB * n_rows + r] = thr ? thr[r] : 0.0;
+    out[SDRK_FEAT_PEAK_SPACING_STD_HZ * n_rows + r] = spacing;
+    out[SDRK_FEAT_PEAK_DENSITY * n_rows + r] = (double)k_all / (double)(nfft > 1 ? nfft : 1);
+    outi[SDRK_FEAT_ARGMAX * n_rows + r] = (long long)s[14];
+    outi[SDRK_FEAT_PEAK_COUNT * n_rows + r] = k_all;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const long long lo = (long long)s[8 + 2 * j], hi = (long long)s[9 + 2 * j];
+        outi[(SDRK_FEAT_OCCUPIED_BINS + 2 * j) * n_rows + 2 * r] = lo;
+        outi[(SDRK_FEAT_OCCUPIED_BINS + 2 * j) * n_rows + 2 * r + 1] = hi;
+        // an all-NaN row has no bin >= max - x: the scans return first > last, the reference 0.0 (:166-168)
+        const bool ok = freqs && 0 <= lo && lo <= hi && hi < nfft;
+        out[(SDRK_FEAT_BANDWIDTH_HZ + j) * n_rows + r] = ok ? freqs[hi] - freqs[lo] : 0.0;
+    }
+}
+
+hipError_t launch_feature_finalize(const double* d_stats, const double* d_thr, const int* d_idx, const int* d_cnt,
+                                   size_t n_rows, int nfft, float gamma, int max_peaks, const double* d_freqs,
+                                   double* d_out, hipStream_t s) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(feature_finalize_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, d_stats, d_thr, d_idx,
+                       d_cnt, n_rows, nfft, gamma, max_peaks, d_freqs, d_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_row_features(const float* d_rows, size_t n_rows, int nfft, int rank, float gamma, int min_distance,

@@ -1283,17 +1283,39 @@ constexpr size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // layout of the packed per-row results in a scratch buffer
 struct FeatLayout {
-    size_t rows_off, stats_off, thr_off, idx_off, cnt_off, total;
-    FeatLayout(size_t n_rows, int nfft, int max_peaks, bool stage_rows, bool peaks) {
+    size_t rows_off, stats_off, thr_off, idx_off, cnt_off, planes_off, freqs_off, total;
+    FeatLayout(size_t n_rows, int nfft, int max_peaks, bool stage_rows, bool peaks, bool planes = false) {
         size_t o = 0;
         rows_off = o;  o += stage_rows ? align256(n_rows * (size_t)nfft * sizeof(float)) : 0;
         stats_off = o; o += align256(n_rows * 16 * sizeof(double));
         thr_off = o;   o += align256(n_rows * sizeof(double));
         idx_off = o;   o += peaks ? align256(n_rows * (size_t)max_peaks * sizeof(int)) : 0;
         cnt_off = o;   o += peaks ? align256(n_rows * sizeof(int)) : 0;
+        planes_off = o; o += planes ? align256(n_rows * SDRK_FEAT_PLANES * sizeof(double)) : 0;
+        freqs_off = o;  o += planes ? align256((size_t)nfft * sizeof(double)) : 0;
         total = o;
     }
 };
+
+// the packed results of a batch -> finished planes (feature_finalize_kernel) -> the caller's host arrays
+int planes_to_host(char* base, const FeatLayout& L, bool peaks, size_t n_rows, int nfft, float gamma, int max_peaks,
+                   const double* freqs, void* out_planes, int32_t* out_idx, hipStream_t s) {
+    const double* d_freqs = nullptr;
+    if (freqs) {
+        HIP_TRY(hipMemcpyAsync(base + L.freqs_off, freqs, (size_t)nfft * sizeof(double), hipMemcpyHostToDevice, s));
+        d_freqs = reinterpret_cast<const double*>(base + L.freqs_off);
+    }
+    hipError_t e = sdrk::launch_feature_finalize(reinterpret_cast<const double*>(base + L.stats_off),
+                                                 reinterpret_cast<const double*>(base + L.thr_off),
+                                                 peaks ? reinterpret_cast<const int*>(base + L.idx_off) : nullptr,
+                                                 peaks ? reinterpret_cast<const int*>(base + L.cnt_off) : nullptr, n_rows, nfft,
+                                                 gamma, max_peaks, d_freqs, reinterpret_cast<double*>(base + L.planes_off), s);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "feature finalize launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(out_planes, base + L.planes_off, n_rows * SDRK_FEAT_PLANES * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (peaks)
+        HIP_TRY(hipMemcpyAsync(out_idx, base + L.idx_off, n_rows * (size_t)max_peaks * sizeof(int), hipMemcpyDeviceToHost, s));
+    return SDRK_OK;
+}
 
 int device_cus(int device, int* cus) {
     hipDeviceProp_t prop;
@@ -1304,14 +1326,15 @@ int device_cus(int device, int* cus) {
 
 }  // namespace
 
-int sdrk_row_features(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
+namespace {
+int row_features_impl(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
                       float gamma, int min_distance, int max_peaks, double* out_stats, double* out_thr,
-                      int32_t* out_idx, int32_t* out_count) {
+                      int32_t* out_idx, int32_t* out_count, const double* freqs, void* out_planes) {
     if (n_rows == 0) return SDRK_OK;
-    if (!rows || !out_stats) return fail(SDRK_ERR_INVALID, "rows or out_stats is NULL");
+    if (!rows || (!out_stats && !out_planes)) return fail(SDRK_ERR_INVALID, "rows or the result pointer is NULL");
     if (nfft < 1) return fail(SDRK_ERR_INVALID, "nfft must be >= 1");
     const bool peaks = out_idx != nullptr || out_count != nullptr;
-    if (peaks && (!out_idx || !out_count || max_peaks < 1 || min_distance < 1))
+    if (peaks && (!out_idx || (!out_count && !out_planes) || max_peaks < 1 || min_distance < 1))
         return fail(SDRK_ERR_INVALID, "peaks need out_idx, out_count and max_peaks, min_distance >= 1");
     int st = check_device(device);
     if (st != SDRK_OK) return st;
@@ -1320,7 +1343,7 @@ int sdrk_row_features(int device, const float* rows, int rows_on_device, size_t 
     st = device_cus(device, &cus);
     if (st != SDRK_OK) return st;
     RowScratchGuard g(device);
-    const FeatLayout L(n_rows, nfft, max_peaks, !rows_on_device, peaks);
+    const FeatLayout L(n_rows, nfft, max_peaks, !rows_on_device, peaks, out_planes != nullptr);
     st = g.reserve(device, L.total);
     if (st != SDRK_OK) return st;
     char* base = static_cast<char*>(g.rs->buf);
@@ -1336,6 +1359,12 @@ int sdrk_row_features(int device, const float* rows, int rows_on_device, size_t 
                                              peaks ? reinterpret_cast<int*>(base + L.idx_off) : nullptr,
                                              peaks ? reinterpret_cast<int*>(base + L.cnt_off) : nullptr, cus, nullptr);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "row_features launch failed: %s", hipGetErrorString(e));
+    if (out_planes) {
+        st = planes_to_host(base, L, peaks, n_rows, nfft, gamma, max_peaks, freqs, out_planes, out_idx, nullptr);
+        if (st != SDRK_OK) return st;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return SDRK_OK;
+    }
     HIP_TRY(hipMemcpy(out_stats, base + L.stats_off, n_rows * 16 * sizeof(double), hipMemcpyDeviceToHost));
     if (out_thr) HIP_TRY(hipMemcpy(out_thr, base + L.thr_off, n_rows * sizeof(double), hipMemcpyDeviceToHost));
     if (peaks) {
@@ -1343,6 +1372,22 @@ int sdrk_row_features(int device, const float* rows, int rows_on_device, size_t 
         HIP_TRY(hipMemcpy(out_count, base + L.cnt_off, n_rows * sizeof(int), hipMemcpyDeviceToHost));
     }
     return SDRK_OK;
+}
+}  // namespace
+
+int sdrk_row_features(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
+                      float gamma, int min_distance, int max_peaks, double* out_stats, double* out_thr,
+                      int32_t* out_idx, int32_t* out_count) {
+    return row_features_impl(device, rows, rows_on_device, n_rows, nfft, rank, gamma, min_distance, max_peaks, out_stats,
+                             out_thr, out_idx, out_count, nullptr, nullptr);
+}
+
+int sdrk_row_features_planes(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
+                             float gamma, int min_distance, int max_peaks, const double* freqs, void* out_planes,
+                             int32_t* out_idx) {
+    if (n_rows && !out_planes) return fail(SDRK_ERR_INVALID, "out_planes is NULL");
+    return row_features_impl(device, rows, rows_on_device, n_rows, nfft, rank, gamma, min_distance, max_peaks, nullptr,
+                             nullptr, out_idx, nullptr, freqs, out_planes);
 }
 
 int sdrk_row_stats(int device, const float* rows, int rows_on_device, size_t n_rows, int nfft, int rank,
@@ -1431,13 +1476,14 @@ int sdrk_frame_features_device(sdrk_plan* p, const void* d_iq, size_t n_frames, 
     return SDRK_OK;
 }
 
-int sdrk_frame_features_host(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride, int rank,
+namespace {
+int frame_features_host_impl(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride, int rank,
                              float gamma, int min_distance, int max_peaks, double* out_stats, double* out_thr,
-                             int32_t* out_idx, int32_t* out_count, float* out_db) {
-    int st = check_exec_args(p, iq, n_frames, frame_stride, out_stats);
+                             int32_t* out_idx, int32_t* out_count, float* out_db, const double* freqs, void* out_planes) {
+    int st = check_exec_args(p, iq, n_frames, frame_stride, out_planes ? out_planes : static_cast<void*>(out_stats));
     if (st != SDRK_OK || n_frames == 0) return st;
     const bool peaks = out_idx != nullptr || out_count != nullptr;
-    if (peaks && (!out_idx || !out_count || max_peaks < 1 || min_distance < 1))
+    if (peaks && (!out_idx || (!out_count && !out_planes) || max_peaks < 1 || min_distance < 1))
         return fail(SDRK_ERR_INVALID, "peaks need out_idx, out_count and max_peaks, min_distance >= 1");
     HIP_TRY(hipSetDevice(p->device));
     const size_t nfft = (size_t)p->nfft;
@@ -1445,7 +1491,7 @@ int sdrk_frame_features_host(sdrk_plan* p, const void* iq, size_t n_frames, size
     // results (and the rows, when the caller wants them or the frame length has no fused kernel) in a second
     // staging buffer that only grows
     const bool need_rows = out_db != nullptr;
-    const FeatLayout L(n_frames, p->nfft, max_peaks, need_rows, peaks);
+    const FeatLayout L(n_frames, p->nfft, max_peaks, need_rows, peaks, out_planes != nullptr);
     void*& fbuf = p->d_feat;
     st = grow(p->device, &fbuf, &p->feat_cap, L.total);
     if (st != SDRK_OK) return st;
@@ -1517,17 +1563,51 @@ int sdrk_frame_features_host(sdrk_plan* p, const void* iq, size_t n_frames, size
             s.user_out = nullptr;
         }
     }
-    HIP_TRY(hipMemcpyAsync(out_stats, base + L.stats_off, n_frames * 16 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    if (out_thr) HIP_TRY(hipMemcpyAsync(out_thr, base + L.thr_off, n_frames * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    if (peaks) {
-        HIP_TRY(hipMemcpyAsync(out_idx, base + L.idx_off, n_frames * (size_t)max_peaks * sizeof(int), hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipMemcpyAsync(out_count, base + L.cnt_off, n_frames * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    // the results come back through ONE exit: whatever fails from here on, no chunk of the pipelined form may still be
+    // using its staging slot when the call returns (a later sdrk_exec_host would restage it under the copy engine)
+    auto results = [&]() -> int {
+        if (out_planes) {
+            int r = planes_to_host(base, L, peaks, n_frames, p->nfft, gamma, max_peaks, freqs, out_planes, out_idx, p->stream);
+            if (r != SDRK_OK) return r;
+        } else {
+            HIP_TRY(hipMemcpyAsync(out_stats, base + L.stats_off, n_frames * 16 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+            if (out_thr) HIP_TRY(hipMemcpyAsync(out_thr, base + L.thr_off, n_frames * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+            if (peaks) {
+                HIP_TRY(hipMemcpyAsync(out_idx, base + L.idx_off, n_frames * (size_t)max_peaks * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+                HIP_TRY(hipMemcpyAsync(out_count, base + L.cnt_off, n_frames * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+            }
+        }
+        if (need_rows)
+            HIP_TRY(hipMemcpyAsync(out_db, base + L.rows_off, n_frames * nfft * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return SDRK_OK;
+    };
+    st = results();
+    if (st != SDRK_OK) {
+        if (p->s_h2d) slots_abandon(p);
+        else (void)hipStreamSynchronize(p->stream);
+        for (auto& s : p->slot) s.busy = false;
+        return st;
     }
-    if (need_rows)
-        HIP_TRY(hipMemcpyAsync(out_db, base + L.rows_off, n_frames * nfft * sizeof(float), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
     for (auto& s : p->slot) s.busy = false;                      // the pipelined form's chunks are all through
     return fused_check(p);
+}
+}  // namespace
+
+int sdrk_frame_features_host(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride, int rank,
+                             float gamma, int min_distance, int max_peaks, double* out_stats, double* out_thr,
+                             int32_t* out_idx, int32_t* out_count, float* out_db) {
+    if (p && n_frames && !out_stats) return fail(SDRK_ERR_INVALID, "input or output pointer is NULL");
+    return frame_features_host_impl(p, iq, n_frames, frame_stride, rank, gamma, min_distance, max_peaks, out_stats, out_thr,
+                                    out_idx, out_count, out_db, nullptr, nullptr);
+}
+
+int sdrk_frame_features_host_planes(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame_stride, int rank,
+                                    float gamma, int min_distance, int max_peaks, const double* freqs, void* out_planes,
+                                    int32_t* out_idx, float* out_db) {
+    if (p && n_frames && !out_planes) return fail(SDRK_ERR_INVALID, "input or output pointer is NULL");
+    return frame_features_host_impl(p, iq, n_frames, frame_stride, rank, gamma, min_distance, max_peaks, nullptr, nullptr,
+                                    out_idx, nullptr, out_db, freqs, out_planes);
 }
 
 /* ---- waterfall ring ------------------------------------------------------ */

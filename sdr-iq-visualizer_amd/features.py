@@ -111,56 +111,37 @@ def _assemble(stats, thr, idx, cnt, nfft: int, freqs, percentile: float, max_pea
     return out
 
 
-def _assemble_arrays(stats, thr, idx, cnt, nfft: int, freqs, percentile: float, max_peaks: int) -> dict:
-    """The same quantities as ``_assemble`` for all rows at once: a dict of arrays (one entry per row), no per-row
-    Python objects — for batches of thousands of rows, where building a dict per row costs more than measuring it."""
-    n_rows = stats.shape[0]
-    mx32 = stats[:, 0].astype(np.float32)
-    nf32 = _percentile_from_order_stats(nfft, percentile, stats[:, 1], stats[:, 2])
-    with np.errstate(all="ignore"):
-        sigma = np.sqrt(stats[:, 4])
-        kurt = np.where(sigma < 1e-9, 0.0, stats[:, 5] / (stats[:, 4] * stats[:, 4]))
-        out = {
-            "max_db": mx32.astype(np.float64),
-            "argmax": stats[:, 14].astype(np.int64),
-            "noise_floor_db": nf32.astype(np.float64),
-            "snr_db": (mx32 - nf32).astype(np.float64),                                        # :46 (float32)
-            "spectral_flatness": np.clip(np.exp(stats[:, 6]) / stats[:, 7], 0.0, 1.0),       # :186-189
-            "spectral_kurtosis": kurt,                                                        # :195-198
-            "adaptive_threshold_db": np.asarray(thr, dtype=np.float64),
-            "peak_count": np.asarray(cnt, dtype=np.int64),
-        }
-    # (rows, max_peaks): row r holds min(peak_count[r], max_peaks) indices, then -1 (the host entry points clear the table)
-    held = np.minimum(out["peak_count"], max_peaks)
-    out["peak_idx"] = idx
-    lo = stats[:, (8, 10, 12)].astype(np.int64)
-    hi = stats[:, (9, 11, 13)].astype(np.int64)
+def _plane_arrays(n_rows: int, max_peaks: int):
+    """The caller-side memory of the ``*_planes`` entry points: SDRK_FEAT_PLANES x n_rows 8-byte words + the peak table."""
+    return np.empty((_ffi.FEAT_PLANES, n_rows), dtype=np.float64), np.empty((n_rows, max_peaks), dtype=np.int32)
+
+
+def _arrays_from_planes(planes: np.ndarray, idx: np.ndarray, with_freqs: bool) -> dict:
+    """One dict of arrays (entry r = row r) over the planes the library filled (include/sdrk.h, SDRK_FEAT_*): views, no
+    per-row Python objects and no arithmetic — the per-row finals of classifier.py:45-58 are formed on the device
+    (feature_finalize_kernel).  Same keys as the per-row dicts of ``_assemble``; ``peak_idx`` is ``(rows, max_peaks)``,
+    row r holding min(peak_count[r], max_peaks) indices, then -1."""
+    n_rows = planes.shape[1]
+    ints = planes.view(np.int64)
+    out = {
+        "max_db": planes[_ffi.FEAT_MAX_DB],
+        "argmax": ints[_ffi.FEAT_ARGMAX],
+        "noise_floor_db": planes[_ffi.FEAT_NOISE_FLOOR_DB],
+        "snr_db": planes[_ffi.FEAT_SNR_DB],                                  # :46
+        "spectral_flatness": planes[_ffi.FEAT_FLATNESS],                     # :186-189
+        "spectral_kurtosis": planes[_ffi.FEAT_KURTOSIS],                     # :195-198
+        "adaptive_threshold_db": planes[_ffi.FEAT_THRESHOLD_DB],             # :55
+        "peak_count": ints[_ffi.FEAT_PEAK_COUNT],
+        "peak_idx": idx,
+    }
     for j, name in enumerate(("3db", "10db", "20db")):
-        out[f"occupied_bins_{name}"] = np.stack([lo[:, j], hi[:, j]], axis=1)
-    if freqs is not None:
-        f = np.asarray(freqs, dtype=np.float64)
-        ok = (0 <= lo) & (lo <= hi) & (hi < nfft)                  # an all-NaN row has first > last: 0 Hz (:166-168)
-        bw = np.where(ok, f[np.clip(hi, 0, nfft - 1)] - f[np.clip(lo, 0, nfft - 1)], 0.0)
+        p = _ffi.FEAT_OCCUPIED_BINS + 2 * j
+        out[f"occupied_bins_{name}"] = ints[p:p + 2].reshape(n_rows, 2)
+    if with_freqs:
         for j, name in enumerate(("3db", "10db", "20db")):
-            out[f"bandwidth_hz_{name}"] = bw[:, j]
-        # np.std(np.diff(f[peaks])) per row (:214-219), 0 for fewer than three peaks: masked two-pass form
-        # (few temporaries: at 32768 rows x 64 slots every extra pass over the table costs as much as a millisecond
-        # of PCIe time)
-        k = held
-        if max_peaks > 1:
-            valid = np.arange(max_peaks - 1)[None, :] < (k[:, None] - 1)
-            pf = f.take(idx, mode="clip")
-            d = pf[:, 1:] - pf[:, :-1]
-            d *= valid
-            m = np.maximum(k - 1, 1)
-            mean = d.sum(axis=1) / m
-            d -= mean[:, None]
-            d *= valid
-            var = np.einsum("ij,ij->i", d, d) / m
-        else:
-            var = np.zeros(n_rows)
-        out["peak_spacing_std_hz"] = np.where(k >= 3, np.sqrt(var), 0.0)
-        out["peak_density"] = out["peak_count"] / max(nfft, 1)
+            out[f"bandwidth_hz_{name}"] = planes[_ffi.FEAT_BANDWIDTH_HZ + j]  # :169-170
+        out["peak_spacing_std_hz"] = planes[_ffi.FEAT_PEAK_SPACING_STD_HZ]    # :214-219
+        out["peak_density"] = planes[_ffi.FEAT_PEAK_DENSITY]
     return out
 
 
@@ -187,14 +168,23 @@ def row_features(power_db, freqs=None, *, device: int = 0, percentile: float = 2
         if rows.ndim != 2 or rows.shape[1] < 1:
             raise ValueError(f"expected (N,) or (R, N) rows, got {rows.shape}")
         ptr, (n_rows, nfft), on_device = rows.ctypes.data_as(c_void_p), rows.shape, False
+    if as_arrays:
+        planes, idx = _plane_arrays(n_rows, max_peaks)
+        f = None if freqs is None else np.ascontiguousarray(freqs, dtype=np.float64)
+        if f is not None and f.shape != (nfft,):
+            raise ValueError(f"freqs must hold one frequency per bin ({nfft}), got {f.shape}")
+        check(lib().sdrk_row_features_planes(device, ptr, int(on_device), ctypes.c_size_t(n_rows), nfft,
+                                             percentile_rank(nfft, percentile),
+                                             ctypes.c_float(float(percentile_gamma(nfft, percentile))), max(3, nfft // 300),
+                                             max_peaks, None if f is None else f.ctypes.data_as(c_void_p),
+                                             planes.ctypes.data_as(c_void_p), idx.ctypes.data_as(c_void_p)))
+        return _arrays_from_planes(planes, idx, f is not None)
     stats, thr, idx, cnt = _result_arrays(n_rows, max_peaks)
     check(lib().sdrk_row_features(device, ptr, int(on_device), ctypes.c_size_t(n_rows), nfft,
                                   percentile_rank(nfft, percentile), ctypes.c_float(float(percentile_gamma(nfft, percentile))),
                                   max(3, nfft // 300), max_peaks,                                   # :56
                                   stats.ctypes.data_as(c_void_p), thr.ctypes.data_as(c_void_p),
                                   idx.ctypes.data_as(c_void_p), cnt.ctypes.data_as(c_void_p)))
-    if as_arrays:
-        return _assemble_arrays(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
     res = _assemble(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
     return res[0] if one else res
 
@@ -216,8 +206,19 @@ def frame_features(samples, sample_rate: float, center_freq: float, *, window=No
     n_rows, nfft = x.shape
     plan = _cached_plan(nfft, window, eps, True, device)
     freqs = freq_axis(nfft, sample_rate, center_freq)
-    stats, thr, idx, cnt = _result_arrays(n_rows, max_peaks)
     rows = np.empty((n_rows, nfft), dtype=np.float32) if return_rows else None
+    if as_arrays:
+        planes, idx = _plane_arrays(n_rows, max_peaks)
+        with plan._lock:
+            check(lib().sdrk_frame_features_host_planes(plan.handle, x.ctypes.data_as(c_void_p), ctypes.c_size_t(n_rows),
+                                                        ctypes.c_size_t(nfft), percentile_rank(nfft, percentile),
+                                                        ctypes.c_float(float(percentile_gamma(nfft, percentile))),
+                                                        max(3, nfft // 300), max_peaks, freqs.ctypes.data_as(c_void_p),
+                                                        planes.ctypes.data_as(c_void_p), idx.ctypes.data_as(c_void_p),
+                                                        rows.ctypes.data_as(c_void_p) if rows is not None else None))
+        res = _arrays_from_planes(planes, idx, True)
+        return (res, rows) if return_rows else res
+    stats, thr, idx, cnt = _result_arrays(n_rows, max_peaks)
     with plan._lock:
         check(lib().sdrk_frame_features_host(plan.handle, x.ctypes.data_as(c_void_p), ctypes.c_size_t(n_rows),
                                              ctypes.c_size_t(nfft), percentile_rank(nfft, percentile),
@@ -226,11 +227,8 @@ def frame_features(samples, sample_rate: float, center_freq: float, *, window=No
                                              stats.ctypes.data_as(c_void_p), thr.ctypes.data_as(c_void_p),
                                              idx.ctypes.data_as(c_void_p), cnt.ctypes.data_as(c_void_p),
                                              rows.ctypes.data_as(c_void_p) if rows is not None else None))
-    if as_arrays:
-        res = _assemble_arrays(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
-    else:
-        res = _assemble(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
-        res = res[0] if one else res
+    res = _assemble(stats, thr, idx, cnt, nfft, freqs, percentile, max_peaks)
+    res = res[0] if one else res
     if return_rows:
         return res, (rows[0] if one else rows)
     return res

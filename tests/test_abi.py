@@ -42,9 +42,21 @@ def test_ctypes_table_matches_header():
 def test_version_and_error_string_without_gpu():
     from sdr_iq_visualizer_amd import _ffi
     lib = _ffi.lib()
-    assert lib.sdrk_version() == 200
+    header = int(re.search(r"#define\s+SDRK_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.sdrk_version() == header == _ffi.ABI_VERSION == 400
     assert isinstance(lib.sdrk_last_error(), bytes)
     assert lib.sdrk_device_count() >= 0
+
+
+def test_stale_library_is_refused_with_a_clear_message(monkeypatch):
+    """A libsdrk.so built from an older header must not surface as an AttributeError on some newer symbol."""
+    from sdr_iq_visualizer_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "ABI_VERSION", 401)
+    with pytest.raises(ImportError, match="reports ABI version 400, this package expects 401"):
+        _ffi.lib()
+    monkeypatch.setattr(_ffi, "ABI_VERSION", 400)
+    assert _ffi.lib().sdrk_version() == 400
 
 
 def test_product_path_fails_loudly_without_a_device():
@@ -90,7 +102,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     exe = _build_c_smoke(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    assert "sdrk 200" in out.stdout
+    assert "sdrk 400" in out.stdout
 
 
 @pytest.mark.gpu

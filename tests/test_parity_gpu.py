@@ -727,6 +727,78 @@ def test_row_features_vs_reference_on_corner_rows(pkg, golden):
         assert same(got["peak_spacing_std_hz"], s[8]), k
 
 
+def _row_of(arrays, r):
+    """Row r of the array form (features.*(as_arrays=True)) as the per-row dict the reference-side checks read."""
+    d = {k: v[r] for k, v in arrays.items() if k != "peak_idx"}
+    d["peak_idx"] = arrays["peak_idx"][r][: min(int(arrays["peak_count"][r]), arrays["peak_idx"].shape[1])]
+    return d
+
+
+def test_row_features_array_form_vs_reference_classifier_helpers(pkg, golden):
+    """f1, array form (round 4): the per-row finals of classifier.py:45-58 are formed ON THE DEVICE
+    (feature_finalize_kernel -> SDRK_FEAT_* planes) and the host only makes views.  Against what the reference's helpers
+    returned: exact where the per-row dict form is exact (noise floor, SNR, bandwidths, threshold, peaks, argmax),
+    1e-9 for the float64 finals (kurtosis, peak spacing), the flatness bar as everywhere."""
+    from sdr_iq_visualizer_amd import features
+    g = golden["ref_classifier_features"]
+    names = [str(n) for n in g["names"]]
+    rows = np.stack([g[f"{k}/power_db"] for k in names])
+    arr = features.row_features(rows, g["freqs"], as_arrays=True, max_peaks=512)
+    assert arr["peak_idx"].shape == (len(names), 512) and arr["max_db"].dtype == np.float64 and arr["argmax"].dtype == np.int64
+    for r, k in enumerate(names):
+        got, s = _row_of(arr, r), g[f"{k}/scalars"]
+        assert got["noise_floor_db"] == s[0] and got["snr_db"] == s[1], k
+        assert (got["bandwidth_hz_3db"], got["bandwidth_hz_10db"], got["bandwidth_hz_20db"]) == (s[2], s[3], s[4]), k
+        assert abs(got["spectral_flatness"] - s[5]) <= FLATNESS_TOL * max(1.0, abs(s[5])), k
+        assert abs(got["spectral_kurtosis"] - s[6]) <= 1e-9 * max(1.0, abs(s[6])), k
+        assert got["adaptive_threshold_db"] == s[7], k
+        assert np.array_equal(got["peak_idx"], g[f"{k}/peak_idx"]) and got["peak_count"] == len(g[f"{k}/peak_idx"]), k
+        assert abs(got["peak_spacing_std_hz"] - s[8]) <= 1e-9 * max(1.0, abs(s[8])), (k, got["peak_spacing_std_hz"], s[8])
+        assert got["argmax"] == int(np.argmax(g[f"{k}/power_db"])) and got["max_db"] == float(np.max(g[f"{k}/power_db"]))
+        assert got["peak_density"] == got["peak_count"] / 4096
+        lo, hi = arr["occupied_bins_3db"][r]
+        assert got["bandwidth_hz_3db"] == g["freqs"][hi] - g["freqs"][lo]
+    # without a frequency axis the Hz quantities are absent, everything else is the same
+    bare = features.row_features(rows, as_arrays=True, max_peaks=512)
+    assert "bandwidth_hz_3db" not in bare and "peak_spacing_std_hz" not in bare
+    for key in bare:
+        assert np.array_equal(bare[key], arr[key], equal_nan=True), key
+    # the unused peak slots hold -1, the kept ones the first max_peaks peaks
+    capped = features.row_features(rows, g["freqs"], as_arrays=True, max_peaks=10)
+    for r, k in enumerate(names):
+        ref_idx = g[f"{k}/peak_idx"]
+        assert capped["peak_count"][r] == len(ref_idx)
+        assert np.array_equal(capped["peak_idx"][r][: min(10, len(ref_idx))], ref_idx[:10])
+        assert np.all(capped["peak_idx"][r][len(ref_idx):] == -1)
+
+
+def test_row_features_array_form_on_corner_rows(pkg, golden):
+    """The array form on the 41 corner rows captured from the reference (lengths 1 ... 33000, NaN / -inf bins, ties at
+    the percentile, rows past 385 dB ...): NaN where the reference is NaN, exact where it is exact."""
+    import warnings
+    from sdr_iq_visualizer_amd import features
+    g = golden["ref_classifier_corner_rows"]
+    fs, fc = g["fs_fc"]
+
+    def same(a, b, tol=0.0):
+        return (np.isnan(a) and np.isnan(b)) or a == b or (np.isfinite(a) and np.isfinite(b) and abs(a - b) <= tol * max(1.0, abs(b)))
+
+    for k in (str(n) for n in g["names"]):
+        p, s = g[f"{k}/power_db"], g[f"{k}/scalars"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            arr = features.row_features(p[None, :], cpu_ref.freq_axis(p.shape[0], fs, fc), as_arrays=True,
+                                        max_peaks=max(1, p.shape[0] // 2))
+        got = _row_of(arr, 0)
+        assert same(got["noise_floor_db"], s[0]) and same(got["snr_db"], s[1]), (k, got["noise_floor_db"], s[0])
+        assert (got["bandwidth_hz_3db"], got["bandwidth_hz_10db"], got["bandwidth_hz_20db"]) == (s[2], s[3], s[4]), k
+        assert same(got["spectral_flatness"], s[5], FLATNESS_TOL), (k, got["spectral_flatness"], s[5])
+        assert same(got["spectral_kurtosis"], s[6], 1e-9), (k, got["spectral_kurtosis"], s[6])
+        assert same(got["adaptive_threshold_db"], s[7]), (k, got["adaptive_threshold_db"], s[7])
+        assert np.array_equal(got["peak_idx"], g[f"{k}/peak_idx"]) and got["peak_count"] == len(g[f"{k}/peak_idx"]), k
+        assert same(got["peak_spacing_std_hz"], s[8], 1e-9), (k, got["peak_spacing_std_hz"], s[8])
+
+
 def test_row_features_other_sizes_vs_oracle(pkg):
     from sdr_iq_visualizer_amd import features
     rng = np.random.default_rng(17)
@@ -859,9 +931,11 @@ def test_frame_features_large_batches_are_pipelined_and_equal(pkg, n, frames):
     picks = np.unique(np.concatenate([[0, 1, frames - 1], rng.integers(0, frames, 40)]))
     small = features.frame_features(x[picks], fs, fc, window="hann", max_peaks=48)
     for j, r in enumerate(picks):
-        for key in ("max_db", "argmax", "noise_floor_db", "snr_db", "spectral_flatness", "spectral_kurtosis", "adaptive_threshold_db",
+        for key in ("max_db", "argmax", "noise_floor_db", "snr_db", "spectral_kurtosis", "adaptive_threshold_db",
                     "peak_count", "bandwidth_hz_3db", "bandwidth_hz_10db", "bandwidth_hz_20db", "peak_density"):
             assert small[j][key] == big[key][r], (key, r)
+        # (the per-frame dict takes exp() from numpy, the array form from the device: one ulp apart at most)
+        assert abs(small[j]["spectral_flatness"] - big["spectral_flatness"][r]) <= 1e-14, r
         k = min(small[j]["peak_count"], 48)
         assert np.array_equal(small[j]["peak_idx"], big["peak_idx"][r, :k]), r
         assert abs(small[j]["peak_spacing_std_hz"] - big["peak_spacing_std_hz"][r]) <= 1e-9 * max(1.0, small[j]["peak_spacing_std_hz"]), r
