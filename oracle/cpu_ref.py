@@ -145,6 +145,22 @@ class Waterfall:
         return np.array(self.rows)                           # callbacks.py:182
 
 
+def dashboard_peak_markers(power_db):
+    """The indices update_graphs marks on the spectrum trace (app/dashboard/callbacks.py:148-159): scipy's find_peaks
+    with distance max(5, N//200) and prominence 3, or — without scipy — strict local maxima above median + 5 dB."""
+    power_db = np.asarray(power_db)
+    try:
+        from scipy.signal import find_peaks                       # callbacks.py:150
+        dist = max(5, len(power_db) // 200)                      # :152
+        idx, _ = find_peaks(power_db, distance=dist, prominence=3)   # :153
+        return np.asarray(idx, dtype=np.int64)
+    except ImportError:
+        med = float(np.median(power_db))                          # :156-159
+        return np.array([i for i in range(1, len(power_db) - 1)
+                         if power_db[i] > power_db[i - 1] and power_db[i] > power_db[i + 1] and power_db[i] > med + 5],
+                        dtype=np.int64)
+
+
 def process_frame(samples, sample_rate, center_freq, now=None):
     """The ``plot_data`` dict of app/sdr/streamer.py:119-130."""
     import time

@@ -379,3 +379,65 @@ def test_percentile_rank_and_interpolation_mirror_numpy():
             hi = min(r + 1, n - 1)
             got = features._percentile_from_order_stats(n, q, np.array([s[r]]), np.array([s[hi]]))[0]
             assert got == np.percentile(x, q), (n, q)
+
+
+# ---- f2: the dashboard callback, fed by the shim -----------------------------------------------
+
+def _oracle_streamer(radio):
+    from oracle.make_golden_dashboard import CENTER_FREQ, SAMPLE_RATE
+    return streaming.SpectrumStreamer(radio, SAMPLE_RATE, CENTER_FREQ, compute=cpu_ref.process_frame)
+
+
+def _exact_row(got, ref, what):
+    assert np.array_equal(got, ref), what
+
+
+def test_dashboard_record_replays_through_the_shim_and_the_deque(golden):
+    """Host logic, no reference needed: the streamer shim (oracle transform injected: no GPU here) and the oracle's
+    deque reproduce every call the reference's update_graphs made — which frame it drew, its peak markers, which rows
+    the heatmap held (queue drop-oldest over 105 frames, deque wrap after 100 rows), x frozen, y = range(rows)."""
+    from tests import dashboard_replay
+    g = golden["ref_update_graphs"]
+    seen = {}
+    for sc in dashboard_replay.scenarios(g):
+        seen[sc["name"]] = dashboard_replay.replay(g, sc, _oracle_streamer, lambda nfft: cpu_ref.Waterfall(100), _exact_row)
+    assert seen == {"live4096": 12, "wrap512": 107}
+
+
+def _reference_callback():
+    import os
+    ref = os.environ.get("SDRK_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "app", "dashboard")):
+        pytest.skip("the reference checkout is not here (build container only)")
+    pytest.importorskip("dash")
+    pytest.importorskip("plotly")
+    from oracle import make_golden_dashboard as mk
+    import logging
+    logging.disable(logging.CRITICAL)
+    try:
+        cb, update_graphs = mk.load_callbacks()
+    finally:
+        logging.disable(logging.NOTSET)
+    return mk, cb, update_graphs
+
+
+def test_reference_update_graphs_runs_unchanged_on_the_shim(golden):
+    """The reference's OWN callback (app/dashboard/callbacks.py:95-243, imported here, `adi` mocked), once fed by the
+    reference's streamer and once by sdr_iq_visualizer_amd.streaming.SpectrumStreamer: the same calls draw the same
+    frames, the four figures of every call serialise to the same JSON, and both equal the committed fixture."""
+    mk, cb, update_graphs = _reference_callback()
+    g = golden["ref_update_graphs"]
+    for sc in mk.SCENARIOS:
+        ref_rec, ref_digests = mk.capture(cb, update_graphs, sc)
+        shim_rec, shim_digests = mk.capture(cb, update_graphs, sc, make_streamer=_oracle_streamer)
+        assert ref_digests == shim_digests and len(ref_digests) > 10
+        assert ref_rec["calls"] == shim_rec["calls"]
+        assert np.array_equal(ref_rec["power_db"], shim_rec["power_db"])
+        # ... and the committed record is what the reference produces today
+        k = sc["name"]
+        assert np.array_equal(g[f"{k}/power_db"], ref_rec["power_db"])
+        assert np.array_equal(g[f"{k}/call_frame"], [c["frame"] for c in ref_rec["calls"]])
+        assert np.array_equal(g[f"{k}/peaks_concat"], [v for c in ref_rec["calls"] for v in c["peaks"]])
+        assert np.array_equal(g[f"{k}/z_ids_concat"], [v for c in ref_rec["calls"] for v in c["z_ids"]])
+        assert np.array_equal(g[f"{k}/trace_x"], ref_rec["trace_x"]) and np.array_equal(g[f"{k}/heat_x"], ref_rec["heat_x"])
+        assert json.loads(str(g[f"{k}/call_text_json"])) == [[c["status"], c["cls"]] for c in ref_rec["calls"]]

@@ -666,6 +666,34 @@ def test_streamer_shim_on_gpu(pkg):
     assert len(wf) == min(n, 100) and wf.as_array().shape == (len(wf), 4096)
 
 
+def test_dashboard_record_replays_on_the_gpu_path(pkg, golden):
+    """f2 end to end on the device: the streamer shim (HIP transform) and the device waterfall ring, read the way the
+    dashboard's update_graphs reads them (app/dashboard/callbacks.py:104-190 with INTEGRATION.md's two-line change),
+    reproduce the record of the reference's own callback (tests/golden/ref_update_graphs.npz): the frame each call
+    drew and the heatmap z to 1e-5 of each row's peak, the trace / heatmap x and y exactly, the scipy peak markers
+    index for index; 105 frames into a queue of 100, 107 rows into a ring of 100."""
+    from sdr_iq_visualizer_amd import streaming
+    from tests import dashboard_replay
+    g = golden["ref_update_graphs"]
+    fs, fc = (float(v) for v in g["sample_rate_center_freq"])
+    rings = []
+
+    def make_waterfall(nfft):
+        rings.append(pkg.WaterfallBuffer(nfft, maxlen=100))
+        return rings[-1]
+
+    seen = {}
+    try:
+        for sc in dashboard_replay.scenarios(g):
+            seen[sc["name"]] = dashboard_replay.replay(
+                g, sc, lambda radio: streaming.SpectrumStreamer(radio, int(fs), int(fc)), make_waterfall,
+                lambda got, ref, what: assert_db_parity(got, ref, what=what))
+    finally:
+        for wf in rings:
+            wf.close()
+    assert seen == {"live4096": 12, "wrap512": 107}
+
+
 # spectral flatness = exp(mean ln p) / mean p with p = 10^(x/10): the device forms p per bin with the float32
 # v_exp_f32 on an exactly reduced argument (~1e-7 relative per term) and accumulates in float64; BASELINE.json's bar
 # is 1e-5, the measured differences are < 1e-7.  Everything else of the reductions is exact or float64 (1e-9).

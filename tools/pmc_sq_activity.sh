@@ -1,14 +1,16 @@
 #!/bin/bash
 # Developer helper (GPU box): SQ activity counters of one configuration's kernels, one rocprofv3 --pmc pass per set.
-#   tools/pmc_mem_pipeline.sh "65536 18749 32768 hann" outdir
+#   tools/pmc_sq_activity.sh "65536 18749 32768 hann" outdir
+# (the memory-pipeline counters — TCC / TCP / TA — are tools/pmc_mem_counters.sh's, ONE per pass)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=$1; OUT=${2:-$ROOT/gpurun_out/pmc_mem}
 case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT";; esac
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
-# (TA_* / TCP_* / TCC_* "_sum" counters abort rocprofv3 on this pool — signal 6, then a hang until the box's watchdog
-#  kills the call — so only SQ sets are collected)
+# (round 3 also put several TA_* / TCP_* / TCC_* "_sum" counters into one set here; rocprofiler refused the SET —
+#  "error code 38: Request exceeds the capabilities of the hardware to collect", the TCC block has 4 slots per pass —
+#  and aborted the process.  The counters themselves collect fine one per pass: tools/pmc_mem_counters.sh.)
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
