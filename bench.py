@@ -468,6 +468,23 @@ def numpy_boundary(lib, _ffi, pkg, synth, dev):
                 cpu.append(time.process_time() - c0)
             rec["pageable_host_cpu_ms_per_GiB"] = round(_median(cpu) * 1e3 / gib, 2)
             del xp, rp
+        if bsz == 32768:
+            # library-side placement of the plan's own staging (SDRK_PLAN_TUNE_STAGING) against a plain plan, same
+            # arrays, result reused: does the pairing effect of the resident buffers reach the numpy boundary?
+            from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+            ab = {}
+            for name, kw in (("plain_plan", {}), ("tuned_staging", {"tune_staging": True})):
+                with SpectrumPlan(NFFT, device=dev, **kw) as tp:
+                    tp.spectrum_db(x, out=res)
+                    ts = []
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        tp.spectrum_db(x, out=res)
+                        ts.append(time.perf_counter() - t0)
+                    ab[name] = {"ms_per_call": round(_median(ts) * 1e3, 3), "ms_min": round(min(ts) * 1e3, 3)}
+                    if kw:
+                        ab[name]["probe_ms_3_candidates_per_slot"] = [round(v, 4) for v in tp.staging_probe()]
+            rec["staging_placement"] = ab
         out["by_batch"][f"B{bsz}"] = rec
     out["pinned_what"] = ("input and result in pkg.pinned_empty arrays (sdrk_host_alloc): chunks are DMA'd straight from / to the "
                           "caller's memory; host_cpu = process CPU time (all threads) per GiB of input")

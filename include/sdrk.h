@@ -132,8 +132,15 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind,
  * rows; kept for A/B work like the flag above — measured 20-35 % SLOWER than the serial two-launch form on
  * BASELINE configs 3 and 5 (profiles/r03/overlap_probe.log). */
 #define SDRK_PLAN_OVERLAP_PASSES 0x2u
+/* SDRK_PLAN_TUNE_STAGING: allocate the device staging of the numpy boundary (sdrk_exec_host's chunk slots) at plan
+ * creation and place each slot's row buffer as sdrk_dev_alloc_stream_pair places a resident pair — the fastest of three
+ * candidates under the plan's own transform over one chunk.  Plans whose max_batch needs no chunking are unaffected.
+ * sdrk_plan_staging_probe returns the probe times (3 per slot; n = 0 when nothing was tuned).  Measured on MI355X:
+ * no effect at the shipped chunk size (the 24 MiB pairs are cache resident and the call is PCIe-bound). */
+#define SDRK_PLAN_TUNE_STAGING 0x4u
 int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
                         const float* window, float eps, int shift, unsigned flags, sdrk_plan** out);
+int sdrk_plan_staging_probe(const sdrk_plan* plan, float* probe_ms, int capacity, int* n);
 /* Large-frame plans (nfft >= 2^15) keep their two-pass intermediate in a scratch buffer, and — like the resident
  * input / output pair, see sdrk_dev_alloc_stream_pair — their speed depends a few per cent on WHERE that buffer
  * landed relative to the data (N = 65536 STFT over the same buffers with six different scratch allocations:

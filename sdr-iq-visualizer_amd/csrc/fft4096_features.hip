@@ -25,9 +25,13 @@ __global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kern
     const float2* __restrict__ iq, size_t frame_stride, float* __restrict__ out_db, size_t n_frames,
     const float* __restrict__ window, const float2* __restrict__ tw4096, float eps, int shift, RowFeatParams prm,
     double* __restrict__ stats, double* __restrict__ thr, int* __restrict__ idx, int* __restrict__ cnt) {
-    __shared__ float2 lds[F4K_XCH_ELEMS + F4K_TW_ELEMS];
+    // 16-byte aligned by declaration, not by being the kernel's only LDS object: RowFeatShared::bins is read and written
+    // as 128-bit vectors
+    __shared__ __attribute__((aligned(16))) float2 lds[F4K_XCH_ELEMS + F4K_TW_ELEMS];
     static_assert(F4K_XCH_ELEMS * sizeof(float2) >= F4K_N * sizeof(float) + sizeof(RowFeatShared) + 16,
                   "row + reduction scratch must fit the exchange buffer");
+    static_assert((F4K_N * sizeof(float)) % alignof(RowFeatShared) == 0 && alignof(RowFeatShared) <= 16,
+                  "RowFeatShared sits behind the row at an offset that keeps its alignment");
     float2* __restrict__ tw256 = lds + F4K_XCH_ELEMS;
     float2* __restrict__ tw4k = tw256 + 256;
     float* __restrict__ row = reinterpret_cast<float*>(lds);                                  // 4096 float32

@@ -131,6 +131,8 @@ struct sdrk_plan {
     int col_cus = 0, row_cus = 0;    // 0: serial form
     // sdrk_exec_host pipeline: HOST_SLOTS chunks in flight, each with pinned host and device staging
     HostSlot slot[HOST_SLOTS];
+    float staging_probe_ms[HOST_SLOTS * 3] = {};   // SDRK_PLAN_TUNE_STAGING: the transform over each candidate pairing
+    int staging_probe_n = 0;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     // non-power-of-two lengths (bluestein.hip): inner power-of-two plan of size blu_m
     sdrk_plan* blu_inner = nullptr;
@@ -349,6 +351,55 @@ void slots_abandon(sdrk_plan* p) {   // error path: nothing may still be writing
     (void)hipStreamSynchronize(p->stream);
     (void)hipStreamSynchronize(p->s_d2h);
     for (auto& s : p->slot) s.busy = false;
+}
+
+// SDRK_PLAN_TUNE_STAGING: the numpy boundary's device staging (HOST_SLOTS chunk pairs of ~16 MiB in / 8 MiB out) allocated
+// at plan creation, each slot's row buffer the fastest of three candidates under the plan's own transform over the
+// chunk — the pairing effect of DESIGN.md §4.1 applied to the library's own buffers.  (Measured in round 4: the probe
+// times of the candidates agree to the microsecond and B = 32768 does not move — a 24 MiB pair lives in the L2 /
+// Infinity Cache, where placement levels do not exist, and the kernel is 1.5 % of a PCIe-bound call.  The flag stays
+// for plans whose chunks are made larger.)
+int tune_staging(sdrk_plan* p) {
+    const size_t nfft = (size_t)p->nfft;
+    if (p->blu_inner || p->max_batch * nfft * sizeof(float2) <= 2 * HOST_CHUNK_BYTES) return SDRK_OK;   // small plans: nothing staged in chunks
+    size_t per = HOST_CHUNK_BYTES / (nfft * sizeof(float2));
+    if (per < 1) per = 1;
+    const size_t in_b = per * nfft * sizeof(float2), out_b = per * nfft * sizeof(float);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int st = SDRK_OK;
+    for (int i = 0; i < HOST_SLOTS && st == SDRK_OK; ++i) {
+        HostSlot& s = p->slot[i];
+        st = slot_reserve(p, s, in_b, 0);                        // events, pinned h_in, d_in
+        if (st != SDRK_OK) break;
+        if (hipHostMalloc(&s.h_out, out_b, hipHostMallocDefault) != hipSuccess) { st = fail(SDRK_ERR_NOMEM, "pinned staging"); break; }
+        void* cand[3] = {nullptr, nullptr, nullptr};
+        int best = 0;
+        for (int c = 0; c < 3 && st == SDRK_OK; ++c) {           // earlier candidates stay allocated: each lands elsewhere
+            if (hipMalloc(&cand[c], out_b) != hipSuccess) { st = fail(SDRK_ERR_NOMEM, "device staging"); break; }
+            float t[4] = {0, 0, 0, 0};
+            for (int r = 0; r < 4 && st == SDRK_OK; ++r) {
+                hipError_t e = hipEventRecord(e0, p->stream);
+                if (e == hipSuccess) st = plan_launch(p, s.d_in, per, nfft, cand[c], sdrk::EPI_LOGPSD, p->stream);
+                if (st == SDRK_OK && e == hipSuccess) e = hipEventRecord(e1, p->stream);
+                if (st == SDRK_OK && e == hipSuccess) e = hipEventSynchronize(e1);
+                if (st == SDRK_OK && e == hipSuccess) e = hipEventElapsedTime(&t[r], e0, e1);
+                if (st == SDRK_OK && e != hipSuccess) st = fail(SDRK_ERR_HIP, "staging probe failed: %s", hipGetErrorString(e));
+            }
+            std::sort(t + 1, t + 4);                             // one warm-up, median of three
+            p->staging_probe_ms[i * 3 + c] = t[2];
+            if (t[2] < p->staging_probe_ms[i * 3 + best]) best = c;
+        }
+        for (int c = 0; c < 3; ++c) {
+            if (c == best && st == SDRK_OK) { s.d_out = cand[c]; s.out_cap = out_b; }
+            else if (cand[c]) (void)hipFree(cand[c]);
+        }
+        if (st == SDRK_OK) p->staging_probe_n = (i + 1) * 3;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return st;
 }
 
 // The numpy boundary.  Small calls (the live app's one 4096-sample buffer, streamer.py:114-121): the
@@ -777,7 +828,7 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
                         float eps, int shift, unsigned flags, sdrk_plan** out) {
     if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (flags & ~(unsigned)(SDRK_PLAN_FUSED64K | SDRK_PLAN_OVERLAP_PASSES))
+    if (flags & ~(unsigned)(SDRK_PLAN_FUSED64K | SDRK_PLAN_OVERLAP_PASSES | SDRK_PLAN_TUNE_STAGING))
         return fail(SDRK_ERR_INVALID, "unknown plan flags 0x%x", flags);
     if ((flags & SDRK_PLAN_OVERLAP_PASSES) && (!is_pow2(nfft) || nfft < (1 << 15)))
         return fail(SDRK_ERR_INVALID, "SDRK_PLAN_OVERLAP_PASSES applies to power-of-two nfft >= 32768 (got %d)", nfft);
@@ -941,7 +992,18 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
         memset(p->h_fused_err, 0, FUSED_MAILBOX * 16 * sizeof(unsigned));
     }
 #undef PLAN_TRY
+    if (flags & SDRK_PLAN_TUNE_STAGING) {
+        st = tune_staging(p);
+        if (st != SDRK_OK) { sdrk_plan_destroy(p); return st; }
+    }
     *out = p;
+    return SDRK_OK;
+}
+
+int sdrk_plan_staging_probe(const sdrk_plan* p, float* probe_ms, int capacity, int* n) {
+    if (!p || !n) return fail(SDRK_ERR_INVALID, "plan or n is NULL");
+    *n = p->staging_probe_n;
+    for (int i = 0; i < p->staging_probe_n && i < capacity && probe_ms; ++i) probe_ms[i] = p->staging_probe_ms[i];
     return SDRK_OK;
 }
 

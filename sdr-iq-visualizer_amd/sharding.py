@@ -45,16 +45,34 @@ def rank_range(n_frames: int, rank: int, world_size: int) -> Tuple[int, int]:
 
 
 def spectrum_db_sharded(samples, devices: Sequence[int], *, window=None, eps: float = 1e-12,
-                        shift: bool = True, out: Optional[np.ndarray] = None) -> np.ndarray:
+                        shift: bool = True, out: Optional[np.ndarray] = None, pin="auto") -> np.ndarray:
     """``spectrum_db`` of a ``(B, N)`` batch split over ``devices`` by frame range.  Each device's thread
     drives its own plan — its own pinned pipeline (sdrk_exec_host) — and writes its rows straight into its
-    slice of the one result array (``out`` if given)."""
+    slice of the one result array (``out`` if given).
+
+    ``pin``: what to do with pageable caller arrays (frames and ``out``).  ``"auto"`` (default): staged through the
+    library's pinned slots until reuse of the same arrays has paid for page-locking them, then page-locked for the
+    rest of their life (``hostmem.plan_pinning`` holds the arithmetic; a host-bound multi-GPU batch gets one
+    ``ResourceWarning`` naming ``pinned_empty``); ``True``: page-lock them for this call only
+    (``hostmem.registered``); ``False``: always stage."""
+    from . import hostmem
     from .spectrum import SpectrumPlan, _as_c64, _cached_plan
 
     x = _as_c64(samples)
     if x.ndim != 2:
         raise ValueError("sharding needs a (B, N) batch")
     out = SpectrumPlan._out_array(out, x.shape, np.float32)
+    if pin not in ("auto", True, False):
+        raise ValueError("pin must be 'auto', True or False")
+    if pin is True and x.nbytes:
+        import contextlib
+        with contextlib.ExitStack() as stack:
+            for a in (x, out):
+                if not hostmem.is_pinned(a):
+                    stack.enter_context(hostmem.registered(a))
+            return spectrum_db_sharded(x, devices, window=window, eps=eps, shift=shift, out=out, pin=False)
+    if pin == "auto" and x.nbytes:
+        hostmem.auto_pin([x, out], len(devices), x.nbytes)
     ranges = shard_ranges(x.shape[0], len(devices))
     errors: List[BaseException] = []
 

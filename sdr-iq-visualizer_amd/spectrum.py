@@ -68,7 +68,7 @@ class SpectrumPlan:
 
     def __init__(self, nfft: int, *, window: WindowArg = None, eps: float = 1e-12,
                  shift: bool = True, device: int = 0, max_batch: int = 1 << 30, fused64k: bool = False,
-                 overlap_passes: bool = False):
+                 overlap_passes: bool = False, tune_staging: bool = False):
         nfft = int(nfft)
         pow2 = nfft >= 2 and not (nfft & (nfft - 1))
         if nfft < 2 or nfft > (1 << _ffi.MAX_LOG2_NFFT) or (not pow2 and nfft > (1 << (_ffi.MAX_LOG2_NFFT - 1))):
@@ -89,7 +89,11 @@ class SpectrumPlan:
         self.fused64k = bool(fused64k)
         # overlap_passes: the two passes of a large frame on two streams (slower, kept for A/B)
         self.overlap_passes = bool(overlap_passes)
-        flags = (_ffi.PLAN_FUSED64K if self.fused64k else 0) | (_ffi.PLAN_OVERLAP_PASSES if self.overlap_passes else 0)
+        # tune_staging: the numpy boundary's device staging placed at creation (sdrk.h SDRK_PLAN_TUNE_STAGING; measured:
+        # no effect at the shipped chunk size)
+        self.tune_staging = bool(tune_staging)
+        flags = ((_ffi.PLAN_FUSED64K if self.fused64k else 0) | (_ffi.PLAN_OVERLAP_PASSES if self.overlap_passes else 0) |
+                 (_ffi.PLAN_TUNE_STAGING if self.tune_staging else 0))
         check(lib().sdrk_plan_create_ex(self.device, nfft, c_size_t(int(max_batch)), kind, wptr,
                                         c_float(self.eps), int(self.shift), flags, byref(self._handle)))
 
@@ -247,6 +251,13 @@ class SpectrumPlan:
     def sync(self) -> None:
         check(lib().sdrk_plan_sync(self.handle))
 
+    def staging_probe(self) -> list:
+        """Probe times (ms) of the staging candidates of a ``tune_staging=True`` plan, three per chunk slot; ``[]``
+        when nothing was tuned."""
+        ms, n = (c_float * 16)(), c_int(0)
+        check(lib().sdrk_plan_staging_probe(self.handle, ms, 16, byref(n)))
+        return [float(ms[i]) for i in range(min(int(n.value), 16))]
+
 
 # ---- plan cache for the function API -------------------------------------------
 _plans: dict = {}
@@ -283,7 +294,7 @@ def _nfft_of(samples) -> int:
 
 def spectrum_db(samples, *, window: WindowArg = None, eps: float = 1e-12, shift: bool = True,
                 device: int = 0, devices: Optional[Sequence[int]] = None,
-                out: Optional[np.ndarray] = None) -> np.ndarray:
+                out: Optional[np.ndarray] = None, pin="auto") -> np.ndarray:
     """Power spectrum in dB of one frame ``(N,)`` or a batch ``(B, N)`` of complex IQ.
 
     Equivalent to ``20*np.log10(np.abs(np.fft.fftshift(np.fft.fft(samples*window, axis=-1),
@@ -292,12 +303,13 @@ def spectrum_db(samples, *, window: WindowArg = None, eps: float = 1e-12, shift:
     batch into contiguous frame ranges, one per GPU (no collectives; see
     sharding.py).  ``out``: a float32 array of the result's shape to fill instead of
     allocating (large batches: reusing it saves the page faults and the munmap of a
-    fresh result per call).
+    fresh result per call).  ``pin`` (with ``devices``): how pageable arrays reach several GPUs — ``"auto"`` stages
+    them until reuse has paid for page-locking them (sharding.spectrum_db_sharded, hostmem.plan_pinning).
     """
     nfft = _nfft_of(samples)
     if devices is not None and len(devices) > 1 and np.ndim(samples) == 2:
         from .sharding import spectrum_db_sharded
-        return spectrum_db_sharded(samples, devices, window=window, eps=eps, shift=shift, out=out)
+        return spectrum_db_sharded(samples, devices, window=window, eps=eps, shift=shift, out=out, pin=pin)
     if devices is not None and len(devices) == 1:
         device = devices[0]
     return _cached_plan(nfft, window, eps, shift, device).spectrum_db(samples, out=out)

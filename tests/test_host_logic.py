@@ -94,3 +94,63 @@ def test_tone_is_on_bin():
     t = synth.tone(64, 5.0)
     X = np.fft.fft(t.astype(np.complex128))
     assert int(np.argmax(np.abs(X))) == 5 and abs(abs(X[5]) - 64) < 1e-3
+
+
+# ---- pin="auto": the decision is arithmetic on measured rates (hostmem.plan_pinning), testable without a GPU ------------
+
+def test_pin_decision_arithmetic():
+    import math
+    from sdr_iq_visualizer_amd import hostmem as h
+    gib = 1 << 30
+    # nothing pageable: nothing to decide
+    assert h.plan_pinning(8, 8 * gib, 0.0, 1, 16).mode == "as-is"
+    # with a few copy threads a single call never pays for its own page-locking (87 ms per GiB against 160 / threads) ...
+    for nd in (1, 2, 4, 8):
+        for cores in (4, 8, 16, 256):
+            d = h.plan_pinning(nd, gib, 1.0, 1, cores)
+            assert d.mode == "stage" and d.register_ms > d.staged_ms - d.pinned_ms, (nd, cores)
+    # ... on a single core it does: staging 1 GiB costs that core 160 ms, page-locking it 87
+    assert h.plan_pinning(2, gib, 1.0, 1, 1).mode == "register"
+    # reused buffers: page-locked exactly when the accumulated staging overhead reaches the registration's price
+    for nd, cores in ((8, 16), (4, 16), (2, 8), (1, 16)):
+        first = h.plan_pinning(nd, nd * gib, 1.0, 1, cores)
+        k_star = math.ceil(first.register_ms / (first.staged_ms - first.pinned_ms))
+        assert h.plan_pinning(nd, nd * gib, 1.0, k_star - 1, cores).mode == "stage"
+        assert h.plan_pinning(nd, nd * gib, 1.0, k_star, cores).mode == "register"
+        assert h.plan_pinning(nd, nd * gib, 1.0, k_star + 7, cores).mode == "register"
+    # 8 GPUs, 8 GiB, the 16 cores of the GPU box: the host's staging copies bound the call -> warn once;
+    # one GPU is link-bound and silent; a small batch is silent; half-pinned calls halve the host's share
+    d8 = h.plan_pinning(8, 8 * gib, 1.0, 1, 16)
+    assert d8.host_bound and d8.warn and d8.staged_ms > 4 * d8.pinned_ms
+    d1 = h.plan_pinning(1, gib, 1.0, 1, 16)
+    assert not d1.host_bound and not d1.warn
+    assert not h.plan_pinning(8, gib // 2, 1.0, 1, 16).warn
+    assert h.plan_pinning(8, 8 * gib, 0.5, 1, 16).staged_ms == pytest.approx(d8.staged_ms / 2)
+    # more usable cores than copy threads change nothing; fewer make it worse
+    assert h.plan_pinning(8, 8 * gib, 1.0, 1, 64).staged_ms == d8.staged_ms
+    assert h.plan_pinning(8, 8 * gib, 1.0, 1, 4).staged_ms == pytest.approx(2 * d8.staged_ms)
+
+
+def test_auto_pin_counts_sightings_and_registers_once(monkeypatch):
+    """The bookkeeping around the decision (no GPU: the registration itself is stubbed)."""
+    import warnings
+    from sdr_iq_visualizer_amd import hostmem as h
+    registered = []
+    monkeypatch.setattr(h, "_register_for_life", lambda a: registered.append(a.ctypes.data) or True)
+    monkeypatch.setattr(h, "is_pinned", lambda a: a.ctypes.data in registered)
+    monkeypatch.setattr(h, "_sightings", {})
+    monkeypatch.setattr(h, "_warned", False)
+    x = np.zeros((64, 4096), dtype=np.complex64)
+    out = np.zeros((64, 4096), dtype=np.float32)
+    claimed = 8 << 30                                         # reckon as if the batch were 8 GiB (the arrays stay small)
+    modes = []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(7):
+            modes.append(h.auto_pin([x, out], 8, claimed, cores=16).mode)
+    assert modes == ["stage"] * 4 + ["register", "as-is", "as-is"]
+    assert sorted(registered) == sorted([x.ctypes.data, out.ctypes.data])
+    assert len([m for m in w if issubclass(m.category, ResourceWarning) and "pinned_empty" in str(m.message)]) == 1
+    # a view of somebody else's memory cannot carry the finaliser: it stays staged
+    monkeypatch.undo()
+    assert h._register_for_life(np.frombuffer(bytearray(4096), dtype=np.float32)) is False

@@ -1244,6 +1244,75 @@ def test_overlapped_passes_agree_with_serial_form(pkg):
         SpectrumPlan(4096, overlap_passes=True)                         # one-pass lengths have nothing to overlap
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_auto_pinned_call_equals_the_staged_one(pkg, monkeypatch):
+    """`spectrum_db(devices=[...], pin="auto")` (hostmem.plan_pinning): staged at first, page-locked for the rest of the
+    arrays' life once reuse has paid for it — the same rows bit for bit either way, and the registration is undone when
+    the arrays die.  (8 GPUs cannot be had here: the decision's arithmetic is tests/test_host_logic.py's; this is the
+    mechanism on one device driven by two threads.)"""
+    import gc
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi, hostmem
+    rng = np.random.default_rng(3)
+    x = rand_c64(rng, 6000, 4096, scale=15.0)                     # 187 MiB in: the chunked pipeline on both "devices"
+    staged = pkg.spectrum_db(x, devices=[0, 0], pin=False)
+    assert not pkg.is_pinned(x)
+    assert_db_parity(staged[:64], cpu_ref.spectrum_db(x[:64]), what="sharded staged")
+    out = np.empty((6000, 4096), dtype=np.float32)
+    monkeypatch.setattr(hostmem, "_sightings", {})
+    first = pkg.spectrum_db(x, devices=[0, 0], out=out)           # pin="auto", first sighting: staged
+    assert first is out and np.array_equal(out, staged) and not pkg.is_pinned(x) and not pkg.is_pinned(out)
+    # make page-locking cheap in the reckoning: the next sighting registers
+    monkeypatch.setattr(hostmem, "COSTS", hostmem.HostCosts(register_ms_per_GiB=0.01))
+    out.fill(np.nan)
+    pkg.spectrum_db(x, devices=[0, 0], out=out)
+    assert pkg.is_pinned(x) and pkg.is_pinned(out) and np.array_equal(out, staged)
+    out.fill(np.nan)
+    pkg.spectrum_db(x, devices=[0, 0], out=out)                   # "as-is" now: DMA straight from / to the arrays
+    assert np.array_equal(out, staged)
+    assert np.array_equal(pkg.spectrum_db(x[100:2100], out=out[100:2100]), staged[100:2100])   # any view of them, any entry point
+    px, po = x.ctypes.data, out.ctypes.data
+    del x, out, first
+    gc.collect()
+    lib = _ffi.lib()
+    assert not lib.sdrk_host_is_pinned(ctypes.c_void_p(px), 4096) and not lib.sdrk_host_is_pinned(ctypes.c_void_p(po), 4096)
+    assert not hostmem._auto_registered
+    # pin=True: page-locked for this one call only
+    y = rand_c64(rng, 3000, 4096, scale=15.0)
+    ref = pkg.spectrum_db(y, devices=[0, 0], pin=False)
+    assert np.array_equal(pkg.spectrum_db(y, devices=[0, 0], pin=True), ref) and not pkg.is_pinned(y)
+    with pytest.raises(ValueError):
+        pkg.spectrum_db(y, devices=[0, 0], pin="sometimes")
+
+
+def test_tuned_staging_plan_equals_the_plain_one(pkg):
+    """SDRK_PLAN_TUNE_STAGING: the numpy boundary's chunk slots allocated and placed at plan creation; same rows bit
+    for bit, nine probe times (three candidates for each of the three slots), nothing tuned for a plan that never
+    chunks, unknown flag bits still refused."""
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    rng = np.random.default_rng(77)
+    x = rand_c64(rng, 5000, 4096, scale=9.0)                      # 156 MiB: ten chunks through the three slots
+    with SpectrumPlan(4096, window="hann") as plain, SpectrumPlan(4096, window="hann", tune_staging=True) as tuned:
+        probe = tuned.staging_probe()
+        assert len(probe) == 9 and all(0.0 < v < 50.0 for v in probe) and plain.staging_probe() == []
+        ref = plain.spectrum_db(x)
+        assert np.array_equal(tuned.spectrum_db(x), ref)
+        assert np.array_equal(tuned.fft(x[:1500]), plain.fft(x[:1500]))        # complex rows outgrow the placed buffers: regrown
+        assert np.array_equal(tuned.spectrum_db(x), ref)
+    with SpectrumPlan(4096, window="hann", max_batch=64, tune_staging=True) as small:
+        assert small.staging_probe() == [] and np.array_equal(small.spectrum_db(x[:64]), ref[:64])
+    with SpectrumPlan(65536, window="hann", tune_staging=True) as big:
+        y = rand_c64(rng, 70, 65536, scale=9.0)
+        assert len(big.staging_probe()) == 9
+        assert np.array_equal(big.spectrum_db(y), pkg.spectrum_db(y, window="hann"))
+
+
 def test_pinned_host_arrays_are_not_staged(pkg):
     """Caller arrays in pinned memory (pinned_empty / registered) go through the copy engines directly: same rows, bit
     for bit, as the staged pageable path — either side pinned, both, large and mid-size calls, overlapped frames,
@@ -1551,7 +1620,7 @@ def test_one_process_per_gpu_path_under_torchrun(pkg, tmp_path):
         "dist.barrier(); dist.destroy_process_group()\n")
     nproc = max(1, min(pkg.device_count(), 4))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -1586,7 +1655,7 @@ def test_welch_over_ranks_rccl_all_reduce_under_torchrun(pkg, tmp_path):
         "dist.barrier(); dist.destroy_process_group()\n")
     nproc = max(1, min(pkg.device_count(), 4))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-                        "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "welch ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
