@@ -681,6 +681,11 @@ def main():
         if "RANK" not in os.environ and args.gpus > 1:
             self_launch(args)                        # does not return
         args.gpus = world
+    # ONE JSON line on stdout: libraries print to file descriptor 1 behind Python's back (gloo's "[Gloo] Rank 0 is
+    # connected ..." and RCCL's version banner do), so descriptor 1 points at stderr until the line itself is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     solo = rank == 0 and world == 1
 
     # cpu baseline first: plain numpy, before any GPU runtime is up.  N = 1: this process; N > 1 self-launched:
@@ -976,7 +981,10 @@ def main():
             line["cpu_baseline"] = cpu
         if secondary is not None:
             line["secondary"] = secondary
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()                               # the default (gloo) group: every rank is done with its GPU
         dist.destroy_process_group()

@@ -1769,3 +1769,41 @@ def test_randomised_large_frame_cases(pkg):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_large.py"), "14", "3"], capture_output=True,
                        text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("launcher", ["plain", "torchrun1", "torchrun1_nccl_refused"])
+def test_bench_prints_exactly_one_json_line(launcher):
+    """The driver's contract: rank 0 prints ONE JSON line.  gloo and RCCL write banners to file descriptor 1 behind
+    Python's back, so the bench keeps descriptor 1 on stderr except for the line — checked on a small run, plain and
+    under torch.distributed.run (one rank: the nccl group is formed and proven; and with the rehearsal switch that
+    makes every rank refuse nccl, where the line must say that the barrier ran over gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    bench = os.path.join(REPO, "bench.py")
+    tail = ["--steps", "2", "--warmup", "1", "--frames", "8192", "--no-secondary", "--cpu-seconds", "0",
+            "--parity-frames", "16", "--placement-candidates", "1"]
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    if launcher == "plain":
+        cmd = [sys.executable, bench] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), bench, "--gpus", "1"] + tail
+        if launcher.endswith("refused"):
+            env["SDRK_BENCH_FAIL_NCCL"] = "all"
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and out.stdout.startswith("{"), out.stdout[:400]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["parity_max_rel_err"] <= 1e-5 and line["roofline"]["bound"] == "hbm"
+    backend = line["config"]["rendezvous_backend"]
+    if launcher == "plain":
+        assert backend is None
+    elif launcher == "torchrun1":
+        assert backend == "nccl" and "rendezvous_note" not in line["config"]
+    else:
+        assert backend == "gloo" and "did not come up on any rank" in line["config"]["rendezvous_note"]
