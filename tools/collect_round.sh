@@ -3,7 +3,10 @@
 #   tools/collect_round.sh r02
 # -> gpurun_out/collect_<tag>/ : rocprofv3 evidence (tools/profile_round.sh), the bench line, the size sweep,
 #    the placement probes and N bench processes with and without placement tuning.
-TAG=${1:-r03}
+# SDRK_COLLECT_LIGHT=1: what changed or is quoted this round only — skips the placement micro-probes, the fused-vs-tiled and
+# overlap A/B runs (closed experiments: their logs of the round that ran them stand) and halves the bench-process counts.
+TAG=${1:-r04}
+LIGHT=${SDRK_COLLECT_LIGHT:-0}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/collect_$TAG
 mkdir -p "$OUT"
@@ -12,20 +15,24 @@ echo "== bench (full line)"; python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/be
 echo "== profiles"; bash tools/profile_round.sh $TAG > "$OUT/profile_round.log" 2>&1; cp gpurun_out/prof_$TAG/summary.json "$OUT/rocprof_summary.json"; cp gpurun_out/prof_$TAG/pmc_fetch_write_rows.csv "$OUT/" 2>/dev/null
 for t in bench cfg3 cfg5 n16384 n2p21 n2p22 feat; do cp gpurun_out/prof_$TAG/${t}_trace/*/*kernel_stats.csv "$OUT/${t}_kernel_stats.csv" 2>/dev/null; done
 echo "== size sweep"; python3 tools/size_sweep.py > "$OUT/size_sweep.log" 2>&1
+if [ "$LIGHT" != 1 ]; then
 echo "== placement probes"
 mkdir -p sdr-iq-visualizer_amd/build_tools
 for t in placeprobe queueprobe; do hipcc --offload-arch=gfx950 -O3 -o sdr-iq-visualizer_amd/build_tools/$t sdr-iq-visualizer_amd/csrc/tools/$t.hip 2>/dev/null; done
 { for i in 1 2 3; do ./sdr-iq-visualizer_amd/build_tools/placeprobe 20 3; done; for i in 1 2 3 4; do ./sdr-iq-visualizer_amd/build_tools/queueprobe 19 4; done; } > "$OUT/placeprobe.log" 2>&1
-echo "== 12 bench processes with placement tuning, 6 without"
+fi
+NP=12; NQ=6; [ "$LIGHT" = 1 ] && { NP=6; NQ=3; }
+echo "== $NP bench processes with placement tuning, $NQ without"
 summ() { python3 -c "
 import json,sys
 l=json.loads(sys.stdin.read()); t=l['telemetry']
 print('%.4f  %.4f  %.4f  %.4f  %7.1f  %.4f  sclk_after %s  probe_ms %s chosen %d' % (l['launch_ms']['median'], l['launch_ms']['min'], l['launch_ms']['max'], l['roofline']['frac'], l['roofline']['measured_copy_GBps'], l['roofline']['frac_of_measured_copy'], t['after']['sclk_mhz'], l['placement']['probe_ms'], l['placement']['chosen']))"; }
-{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   (12 processes; placement: 6 candidates)";
+{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   ($NP processes; placement: 6 candidates)";
   echo "# launch_ms median  min  max  frac_of_8TB/s  copy_GB/s  kernel/copy";
-  for i in $(seq 12); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 2>/dev/null | tail -1 | summ; done; } > "$OUT/placement_runs.txt"
-{ echo "# the same with --placement-candidates 1 (plain alloc(in); alloc(out)), 6 processes";
-  for i in $(seq 6); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 --placement-candidates 1 2>/dev/null | tail -1 | summ; done; } > "$OUT/plain_alloc_runs.txt"
+  for i in $(seq $NP); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 2>/dev/null | tail -1 | summ; done; } > "$OUT/placement_runs.txt"
+{ echo "# the same with --placement-candidates 1 (plain alloc(in); alloc(out)), $NQ processes";
+  for i in $(seq $NQ); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 --placement-candidates 1 2>/dev/null | tail -1 | summ; done; } > "$OUT/plain_alloc_runs.txt"
+if [ "$LIGHT" != 1 ]; then
 echo "== fused vs tiled N=65536 (4096 packed frames, then config 3; Hann)"
 { python3 tools/fused_probe.py 4096 65536 hann; python3 tools/fused_probe.py 18749 32768 hann; } > "$OUT/fused64k_vs_tiled.log" 2>&1
 cat "$OUT/fused64k_vs_tiled.log"; tail -3 "$OUT/placement_runs.txt"; tail -3 "$OUT/plain_alloc_runs.txt"
@@ -57,6 +64,10 @@ cat "$OUT/overlap_trace_summary.txt"
 echo "== host link: pageable / registered / pinned copies of 1 GiB in + 0.5 GiB out"
 mkdir -p sdr-iq-visualizer_amd/build_tools
 hipcc --offload-arch=gfx950 -O3 -o sdr-iq-visualizer_amd/build_tools/pcie_probe sdr-iq-visualizer_amd/csrc/tools/pcie_probe.hip 2>/dev/null && ./sdr-iq-visualizer_amd/build_tools/pcie_probe > "$OUT/pcie_probe.log" 2>&1; cat "$OUT/pcie_probe.log"
+fi
+echo "== per-row measurements at the numpy boundary"; python3 tools/feat_host_probe.py > "$OUT/feat_host_probe.log" 2>&1; tail -2 "$OUT/feat_host_probe.log"
+echo "== bench.py under torch.distributed.run, one rank (the nccl group formed and proven)"
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 bench.py --gpus 1 --steps 5 --warmup 1 --no-secondary --cpu-seconds 0 > "$OUT/bench_torchrun1_nccl.json" 2> "$OUT/bench_torchrun1_nccl.err"; echo "rc=$? $(wc -l < "$OUT/bench_torchrun1_nccl.json") line(s)"
 echo "== bench.py --gpus 2, self-launched (rehearsal on one GPU: gloo rendezvous, ranks share the device)"
 python3 bench.py --gpus 2 --steps 3 --warmup 1 --frames 262144 --cpu-seconds 3 --cpu-all-cores-seconds 2 2> "$OUT/bench_gpus2_rehearsal.err" | grep '^{' > "$OUT/bench_gpus2_rehearsal.json"; echo "rc=$? $(wc -c < "$OUT/bench_gpus2_rehearsal.json") bytes"
 echo "== one-frame host call"; python3 tools/small_call_probe.py > "$OUT/small_call_probe.log" 2>&1; cat "$OUT/small_call_probe.log"

@@ -5,7 +5,8 @@
 # MI355X guide prescribes) of the bench and of BASELINE configs 3 and 5.  Outputs under gpurun_out/prof_<tag>/;
 # tools/summarise_profiles.py turns them into the files committed under profiles/<tag>/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
+LIGHT=${SDRK_COLLECT_LIGHT:-0}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -20,7 +21,9 @@ run bench_trace --kernel-trace --stats --output-format csv -d "$OUT/bench_trace"
 run bench_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_fetch" -- python3 "$ROOT/bench.py" $BENCH_SHORT
 run bench_write --pmc WRITE_SIZE --output-format csv -d "$OUT/bench_write" -- python3 "$ROOT/bench.py" $BENCH_SHORT
 # BASELINE configs 3 and 5, and the frame lengths DESIGN.md names as the slowest passes left (not BASELINE configs)
-for cfg in "cfg3 65536 18749 32768 hann" "cfg5 1048576 256 1048576 hann" "n16384 16384 8192 16384 rect" "n2p21 2097152 128 2097152 rect" "n2p22 4194304 64 4194304 rect"; do
+CFGS=("cfg3 65536 18749 32768 hann" "cfg5 1048576 256 1048576 hann" "n16384 16384 8192 16384 rect" "n2p21 2097152 128 2097152 rect" "n2p22 4194304 64 4194304 rect")
+[ "$LIGHT" = 1 ] && CFGS=("cfg3 65536 18749 32768 hann" "cfg5 1048576 256 1048576 hann")   # the BASELINE configs only
+for cfg in "${CFGS[@]}"; do
     set -- $cfg
     run $1_trace --kernel-trace --stats --output-format csv -d "$OUT/$1_trace" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5
     run $1_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/$1_fetch" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5

@@ -30,6 +30,22 @@ def stats(dirname):
     return out
 
 
+def timed_launches(dirname, kernel_prefix, last_n):
+    """From the kernel trace itself (not the --stats average): the LAST `last_n` dispatches of the kernel — bench.py's
+    timed region; what comes before them are the placement probe's launches over candidate pairings and the warm-up."""
+    for f in newest(dirname, "*kernel_trace.csv"):
+        rows = [r for r in csv.DictReader(open(f)) if short(r["Kernel_Name"]).startswith(kernel_prefix)]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        if len(rows) < last_n:
+            return None
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        t, e = dur[-last_n:], dur[:-last_n]
+        return {"timed_launches": last_n, "timed_avg_us": round(sum(t) / len(t), 3), "timed_min_us": round(min(t), 3),
+                "timed_max_us": round(max(t), 3), "earlier_launches": len(e),
+                "earlier_avg_us": round(sum(e) / len(e), 3) if e else None}
+    return None
+
+
 def pmc(dirname, counter):
     acc = defaultdict(list)
     for f in newest(dirname, "*counter_collection.csv"):
@@ -75,6 +91,12 @@ def main(root):
                 rec["WRITE_SIZE_KB_mean"] = round(wr[k]["mean_KB"], 3)
                 rec["write_bytes_per_dispatch"] = round(wr[k]["mean_KB"] * 1024)
             kernels[k] = rec
+        if tag == "bench":       # python3 bench.py --no-secondary --cpu-seconds 0: 20 timed steps (the default --steps)
+            for k in kernels:
+                if k.startswith("fft4096_kernel"):
+                    tl = timed_launches(f"{root}/{tag}_trace", "fft4096_kernel", 20)
+                    if tl:
+                        kernels[k].update(tl)
         counters = sq(root, tag)
         for k, c in counters.items():
             kernels.setdefault(k, {})["sq_counters_mean_per_dispatch"] = c
