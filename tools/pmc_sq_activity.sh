@@ -11,10 +11,11 @@ i=0
 # (round 3 also put several TA_* / TCP_* / TCC_* "_sum" counters into one set here; rocprofiler refused the SET —
 #  "error code 38: Request exceeds the capabilities of the hardware to collect", the TCC block has 4 slots per pass —
 #  and aborted the process.  The counters themselves collect fine one per pass: tools/pmc_mem_counters.sh.)
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
-           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"; do
+# (the SQ block has 8 slots per pass: MI355X_MICROARCH.md "rocprofv3 PMC slots"; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES)
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+           "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/set$i" -- python3 "$ROOT/tools/one_config.py" $CFG > /dev/null 2> "$OUT/set$i.err" || echo "set $i failed: $set"
+  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d "$OUT/set$i" -- python3 "$ROOT/tools/one_config.py" $CFG > /dev/null 2> "$OUT/set$i.err" || { echo "set $i failed: $set"; tail -3 "$OUT/set$i.err"; break; }
 done
 python3 - "$OUT" <<'PY'
 import csv,glob,sys,collections,re

@@ -54,6 +54,18 @@ def one_case(c, rng, done):
         for key, tol in (("spectral_flatness", 1e-6), ("spectral_kurtosis", 1e-9)):
             a, b = got[key], ref[key]
             assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= tol * max(1.0, abs(b)), (c, kind, n, key, a, b)
+        # the array form of the same row (sdrk_row_features_planes: finals formed on the device)
+        arr = features.row_features(x[None, :], freqs, as_arrays=True, max_peaks=4096)
+        for key in ("noise_floor_db", "snr_db", "bandwidth_hz_3db", "bandwidth_hz_10db", "bandwidth_hz_20db", "adaptive_threshold_db",
+                    "spectral_kurtosis", "max_db", "argmax", "peak_count"):
+            a, b = arr[key][0], got[key]
+            assert a == b or (np.isnan(a) and np.isnan(b)), (c, kind, n, key, a, b, "array form")
+        a, b = arr["spectral_flatness"][0], got["spectral_flatness"]
+        assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-14, (c, kind, n, "flatness", a, b)
+        a, b = arr["peak_spacing_std_hz"][0], got["peak_spacing_std_hz"]
+        assert abs(a - b) <= 1e-9 * max(1.0, abs(b)), (c, kind, n, "spacing", a, b)
+        k = min(int(arr["peak_count"][0]), 4096)
+        assert np.array_equal(arr["peak_idx"][0][:k], got["peak_idx"][:k]), (c, kind, n, "array form peaks")
         done[kind] += 1
 
 

@@ -60,6 +60,23 @@ def run(cases, seed):
         blind = features.frame_features(x, fs, fc, window=window)
         assert_db_parity(rows, cpu_ref.spectrum_db(x, window=cpu_ref.hann(n) if window else None), what=f"case {c} rows")
         freqs = cpu_ref.freq_axis(n, fs, fc)
+        # the array form (per-row finals formed on the device): every quantity against the per-frame dicts
+        mp = int(rng.choice([8, 64, 1024]))
+        arr = features.frame_features(x, fs, fc, window=window, as_arrays=True, max_peaks=mp)
+        capped = features.frame_features(x, fs, fc, window=window, max_peaks=mp)
+        for r in range(b):
+            for key in ("max_db", "argmax", "noise_floor_db", "snr_db", "spectral_kurtosis", "adaptive_threshold_db", "peak_count",
+                        "bandwidth_hz_3db", "bandwidth_hz_10db", "bandwidth_hz_20db", "peak_density"):
+                a, e = arr[key][r], capped[r][key]
+                assert a == e or (np.isnan(a) and np.isnan(e)), ((c, r, kinds[r], n, window), key, a, e, "array form")
+            a, e = arr["spectral_flatness"][r], capped[r]["spectral_flatness"]
+            assert (np.isnan(a) and np.isnan(e)) or abs(a - e) <= 1e-14, ((c, r, kinds[r]), "flatness", a, e)
+            a, e = arr["peak_spacing_std_hz"][r], capped[r]["peak_spacing_std_hz"]
+            assert abs(a - e) <= 1e-9 * max(1.0, abs(e)), ((c, r, kinds[r]), "spacing", a, e)
+            k = min(int(arr["peak_count"][r]), mp)
+            assert np.array_equal(arr["peak_idx"][r][:k], capped[r]["peak_idx"]) and np.all(arr["peak_idx"][r][k:] == -1), (c, r)
+            for j, name in enumerate(("3db", "10db", "20db")):
+                assert tuple(arr[f"occupied_bins_{name}"][r]) == capped[r][f"occupied_bins_{name}"], (c, r, name)
         for r in range(b):
             ref = cpu_ref.row_features(freqs, rows[r])
             tag = (c, r, kinds[r], n, window)
