@@ -169,6 +169,8 @@ def _register_for_life(a: np.ndarray) -> bool:
     root = _owner(a)
     if not isinstance(root, np.ndarray) or not root.flags.owndata or not root.flags.c_contiguous or root.nbytes == 0:
         return False
+    if root.nbytes > 2 * a.nbytes:          # a small window of a large allocation: page-locking all of it is not what was asked
+        return False
     ptr, nbytes = root.ctypes.data, root.nbytes
     with _auto_lock:
         if ptr in _auto_registered:

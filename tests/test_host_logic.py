@@ -154,3 +154,5 @@ def test_auto_pin_counts_sightings_and_registers_once(monkeypatch):
     # a view of somebody else's memory cannot carry the finaliser: it stays staged
     monkeypatch.undo()
     assert h._register_for_life(np.frombuffer(bytearray(4096), dtype=np.float32)) is False
+    # ... and a small window of a large allocation is not a reason to page-lock all of it
+    assert h._register_for_life(np.zeros(1 << 16, dtype=np.float32)[:1024]) is False
