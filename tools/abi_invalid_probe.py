@@ -83,6 +83,18 @@ def cases():
     yield "frame_features_host: NULL plan", lib.sdrk_frame_features_host(None, xp, 1, 4096, 800, c_float(0.5), 13, 8, sp, tp, ip, cp, NULL)
     yield "frame_features_host: NULL stats", lib.sdrk_frame_features_host(plan, xp, 1, 4096, 800, c_float(0.5), 13, 8, NULL, tp, ip, cp, NULL)
     yield "frame_features_host: counts without the list", lib.sdrk_frame_features_host(plan, xp, 1, 4096, 800, c_float(0.5), 13, 8, sp, tp, NULL, cp, NULL)
+    planes = np.zeros((_ffi.FEAT_PLANES, 2)); freqs = np.zeros(4096)
+    pp, fp = planes.ctypes.data_as(c_void_p), freqs.ctypes.data_as(c_void_p)
+    yield "frame_features_host_planes: NULL plan", lib.sdrk_frame_features_host_planes(None, xp, 1, 4096, 800, c_float(0.5), 13, 8, fp, pp, ip, NULL)
+    yield "frame_features_host_planes: NULL planes", lib.sdrk_frame_features_host_planes(plan, xp, 1, 4096, 800, c_float(0.5), 13, 8, fp, NULL, ip, NULL)
+    yield "frame_features_host_planes: NULL frames", lib.sdrk_frame_features_host_planes(plan, NULL, 1, 4096, 800, c_float(0.5), 13, 8, fp, pp, ip, NULL)
+    yield "frame_features_host_planes: peak list with max_peaks 0", lib.sdrk_frame_features_host_planes(plan, xp, 1, 4096, 800, c_float(0.5), 13, 0, fp, pp, ip, NULL)
+    yield "row_features_planes: NULL planes", lib.sdrk_row_features_planes(0, rp, 0, 2, 4096, 800, c_float(0.5), 13, 8, fp, NULL, ip)
+    yield "row_features_planes: NULL rows", lib.sdrk_row_features_planes(0, NULL, 0, 2, 4096, 800, c_float(0.5), 13, 8, fp, pp, ip)
+    yield "row_features_planes: no such device", lib.sdrk_row_features_planes(99, rp, 0, 2, 4096, 800, c_float(0.5), 13, 8, fp, pp, ip)
+    yield "row_features_planes: min_distance 0", lib.sdrk_row_features_planes(0, rp, 0, 2, 4096, 800, c_float(0.5), 0, 8, fp, pp, ip)
+    yield "plan_staging_probe: NULL plan", lib.sdrk_plan_staging_probe(None, f3, 3, byref(c_int(0)))
+    yield "plan_staging_probe: NULL count", lib.sdrk_plan_staging_probe(plan, f3, 3, None)
     yield "frame_features_device: NULL stats", lib.sdrk_frame_features_device(plan, d, 1, 4096, NULL, 800, c_float(0.5), 13, 8, NULL, NULL, NULL, NULL, None)
     yield "waterfall_create: nfft 0", lib.sdrk_waterfall_create(0, 0, 10, byref(out_wf))
     yield "waterfall_create: maxlen 0", lib.sdrk_waterfall_create(0, 4096, 0, byref(out_wf))
@@ -108,7 +120,9 @@ def cases():
     yield "copy_probe: zero launches", lib.sdrk_copy_probe(0, d, d, 1024, 0, f3)
     yield "host_link_probe: no such device", lib.sdrk_host_link_probe(99, 1 << 20, None, None, None)
 
-    # the handles still work
+    # the handles still work (and the planes form with neither a frequency axis nor a peak table is a valid call)
+    assert lib.sdrk_frame_features_host_planes(plan, xp, 2, 4096, 800, c_float(0.5), 13, 8, NULL, pp, NULL, NULL) == 0
+    assert np.all(planes[_ffi.FEAT_MAX_DB] == np.float32(-240.00002)) and np.all(planes.view(np.int64)[_ffi.FEAT_PEAK_COUNT] == 0)
     assert lib.sdrk_exec_host(plan, xp, 2, 4096, rp) == 0 and np.all(rows == np.float32(-240.00002))
     assert lib.sdrk_waterfall_append_rows(wf, rp, 2) == 0 and lib.sdrk_waterfall_rows(wf) == 4
     assert lib.sdrk_waterfall_destroy(wf) == 0 and lib.sdrk_plan_destroy(plan) == 0 and lib.sdrk_plan_destroy(plan1k) == 0
