@@ -22,7 +22,8 @@ prints ONE JSON line.  At N = 1 the same line also carries:
   cpu_baseline         the oracle on one core, plus `all_cores` (one worker per CPU this process may use)
   secondary            BASELINE configs 3 and 5 (device resident), the numpy boundary (PCIe inclusive) and
                        the per-row feature reductions — each with its own algorithmic-bytes formula
-`--no-secondary` skips those extra legs (the driver's N > 1 runs skip them by themselves).
+`--no-secondary` skips those extra legs.  At N > 1 the only extra leg is `secondary.config5_channels`: one continuous
+N = 2^20 channel per GPU (BASELINE.json configs[4]), all ranks at the same time, a few tens of milliseconds.
 """
 from __future__ import annotations
 
@@ -903,6 +904,38 @@ def main():
             secondary["row_features"] = feature_reductions(lib, _ffi, SpectrumPlan, features, dev)
         except Exception as e:
             secondary["error"] = f"{type(e).__name__}: {e}"
+    elif dist is not None and not args.no_secondary:
+        # N > 1: BASELINE.json configs[4] as it is worded — one continuous N = 2^20 channel PER GPU, all at the same
+        # time: 256 back-to-back Hann frames from a resident stream -> the device waterfall ring -> max-hold to 4096
+        # bins and a host gather every 16 rows (channel seed = 1234 + device).  Every rank runs its channel between
+        # two barriers; rank 0 reports each channel's sustained rate and whether 61.44 Msps real time holds on all.
+        rec = None
+
+        def rank_barrier():                                      # (the bench's own plan is closed by now)
+            torch.cuda.synchronize()
+            dist.barrier(group=grp, **({"device_ids": [dev]} if backend == "nccl" else {}))
+
+        try:
+            rank_barrier()
+            rec = channel_config5(lib, _ffi, pkg, SpectrumPlan, dev)
+            rank_barrier()
+        except Exception as e:                                   # noqa: BLE001 - a secondary leg never costs the line
+            rec = {"error": f"{type(e).__name__}: {e}"}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, rec)                    # the default (gloo) group: plain Python objects
+        if rank == 0:
+            ok = [r for r in everyone if r and "pipelined" in r]
+            secondary = {"config5_channels": {
+                "workload": "BASELINE.json configs[4]: one continuous N=2^20 channel per GPU, all concurrently "
+                            "(256 frames each, device waterfall ring of 100 rows, decimated host gather every 16 rows)",
+                "channels": world,
+                "per_channel_Msamples_per_s": [r["pipelined"]["Msamples_per_s"] if r and "pipelined" in r else None for r in everyone],
+                "per_channel_ms": [r["pipelined"]["ms"] if r and "pipelined" in r else None for r in everyone],
+                "per_channel_ms_with_every_sync": [r["ms"] if r and "ms" in r else None for r in everyone],
+                "aggregate_Msamples_per_s": round(sum(r["pipelined"]["Msamples_per_s"] for r in ok), 1),
+                "realtime_61.44_Msps_holds_on_every_channel": bool(ok) and len(ok) == world and
+                                                              all(r["pipelined"]["Msamples_per_s"] >= 61.44 for r in ok),
+                "errors": [r["error"] for r in everyone if r and "error" in r] or None}}
 
     if rank == 0:
         samples_per_step = frames * NFFT * world
