@@ -35,7 +35,22 @@ def plan_batch():
         p.spectrum_db(batch)
 def pinned():
     a = pkg.pinned_empty((64, 4096), np.complex64); a[...] = 1; pkg.spectrum_db(a); del a
-kinds = {"waterfall_async": wf_async, "features_batch": lambda: features.frame_features(batch, 1e6, 2.4e9, max_peaks=16, as_arrays=True),
+def tuned():
+    with SpectrumPlan(4096, window="hann", tune_staging=True) as p:
+        p.spectrum_db(batch)
+def auto_pin():                                          # a fresh pair of arrays per cycle, page-locked at once (cheap in the reckoning)
+    from sdr_iq_visualizer_amd import hostmem
+    old, hostmem.COSTS = hostmem.COSTS, hostmem.HostCosts(register_ms_per_GiB=0.001)
+    try:
+        a, o = batch.copy(), np.empty(batch.shape, np.float32)
+        pkg.spectrum_db(a, devices=[0, 0], out=o); pkg.spectrum_db(a, devices=[0, 0], out=o)
+        assert pkg.is_pinned(a)
+        del a, o
+    finally:
+        hostmem.COSTS = old
+    assert not hostmem._auto_registered
+kinds = {"tuned_staging": tuned, "auto_pin": auto_pin, "row_planes": lambda: features.row_features(np.zeros((300, 4096), np.float32), None, as_arrays=True, max_peaks=32),
+         "waterfall_async": wf_async, "features_batch": lambda: features.frame_features(batch, 1e6, 2.4e9, max_peaks=16, as_arrays=True),
          "host_pipeline": plan_batch, "pinned_arrays": pinned,
          "plan4096": plan(4096, window="hann"), "plan1000": plan(1000), "plan8192": plan(8192), "plan65536": plan(65536, window="hann"),
          "fused": plan(65536, fused64k=True), "plan2^20": plan(1 << 20), "waterfall": wf,
