@@ -999,7 +999,7 @@ def main():
             },
             "launch_ms": {"min": round(min(each_ms), 4), "median": round(_median(each_ms), 4),
                           "max": round(max(each_ms), 4), "mean": round(sum(each_ms) / len(each_ms), 4),
-                          "n": len(each_ms), "scope": "rank 0"},
+                          "n": len(each_ms), "scope": "rank 0", "series": [round(float(v), 3) for v in each_ms]},
             "parity_max_rel_err": parity,
             "parity_frames_checked": n_checked,
             "placement": placement,
