@@ -492,6 +492,200 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
     }
 }
 
+// The M = 2048 row pass with ONE WAVE PER ROW (round 4; N = 2^20 ... 2^22, log epilogue).
+//
+// lds_fft_core gives a row to T = M / 16 = 128 threads — two waves — and puts a workgroup barrier around every exchange.
+// In row_pass_pair_kernel<11> that marches all sixteen waves of the one 1024-thread workgroup a CU has room for through
+// load -> transform -> transpose -> store in lockstep: a wave parked at s_waitcnt / s_barrier 40 % of its cycles, VALU
+// 51 % of a SIMD, an L2 channel busy only 63 % of the dispatch — 70 us per 24-frame chunk where its bytes need 47
+// (profiles/r04/cfg5_sq_activity.txt, cfg5_mem_counters.txt).  Here each LANE is two of those 128 threads (tau = lane and
+// lane + 64: 32 points, 64 registers), so that
+//   * a row's exchanges stay inside one wave and need NO barrier: the wave's own LDS queue is the ordering;
+//   * a workgroup is four waves = four rows, 70 KiB of LDS, and TWO workgroups share a CU and overlap each other's
+//     phases — at two waves per SIMD, i.e. 256 registers per wave, which is what lets the dB values of three earlier
+//     four-row steps (3 x 32) wait in registers until the sixteen-row band leaves in 64-byte pieces (the 128-register
+//     forms of this idea needed ~35 registers of spill, and 8-row bands leave in 32-byte pieces: both measured, A.11);
+//   * barriers remain only around the band's transposed store ([M / 2][17] floats: exactly the exchange area, twice).
+// Measured on config 5 (tools/ab_cfg.py, rocprofv3 kernel trace): 69.8 -> 57.6 us per chunk, N = 2^20 1.49 -> 1.40 ms;
+// N = 2^21 / 2^22 packed frames -3 ... -6 %.  Rows equal the pair kernel's to the last bits that the second thread's
+// derived table entries leave (W_N^(tau + 64 + T i) is formed as W_N^(tau + T i) W_N^64: one rounding).
+template <int LOG2N>
+__device__ __forceinline__ void lds_fft_core_wave2(cf (&va)[16], cf (&vb)[16], float2* __restrict__ lds, int taua, int taub,
+                                                   const LdsTw<LOG2N>& twa, const LdsTw<LOG2N>& twb) {
+    using C = LdsCfg<LOG2N>;
+    constexpr int N = C::N, P = C::P, R0 = C::R0, T = C::T, C0 = 16 / R0;
+    static_assert(R0 != 16 && P > 1, "written for the R0 < 16 first pass (M = 2048: 8 x 16 x 16)");
+    auto first = [&](cf (&v)[16], const LdsTw<LOG2N>& tw) {
+#pragma unroll
+        for (int i = 0; i < C0; ++i) small_bfly<R0>(v, i * R0);
+#pragma unroll
+        for (int i = 0; i < C0; ++i) {
+            cf w1 = tw.w0[i], wk = w1;
+#pragma unroll
+            for (int k = 1; k < R0; ++k) {
+                v[i * R0 + k] = cmul(v[i * R0 + k], wk);
+                if (k + 1 < R0) wk = cmul(wk, w1);
+            }
+        }
+    };
+    first(va, twa);
+    first(vb, twb);
+    constexpr int S1 = C::Mp(0) + C::pad(1);
+    auto write1 = [&](const cf (&v)[16], int tau) {
+#pragma unroll
+        for (int i = 0; i < C0; ++i)
+#pragma unroll
+            for (int k = 0; k < R0; ++k) {
+                const cf z = v[i * R0 + k];
+                lds[(tau + T * i) + S1 * k] = make_float2(z.x, z.y);
+            }
+    };
+    write1(va, taua);
+    write1(vb, taub);
+#pragma unroll
+    for (int p = 1; p < P; ++p) {
+        const int Mq = C::Mp(p);
+        const int Sin = C::Mp(p - 1) + C::pad(p);
+        auto read = [&](cf (&v)[16], int tau) {
+            const int Kin = tau / Mq, rr = tau - Kin * Mq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 t = lds[rr + Mq * j + Sin * Kin];
+                v[j] = cf{t.x, t.y};
+            }
+        };
+        __builtin_amdgcn_wave_barrier();       // (scheduling only: the writes above precede the reads below in this wave's LDS queue)
+        read(va, taua);
+        read(vb, taub);
+        radix16(va);
+        radix16(vb);
+        if (p < P - 1) {
+            auto twiddle = [&](cf (&v)[16], const LdsTw<LOG2N>& tw) {
+                cf w[16], w1 = tw.wp[p];
+                asm volatile("" : "+v"(w1.x), "+v"(w1.y));
+                pow_tree(w1, w);
+#pragma unroll
+                for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
+            };
+            twiddle(va, twa);
+            __builtin_amdgcn_sched_barrier(0);     // (one power tree at a time: interleaved, the two cost 32 more registers)
+            twiddle(vb, twb);
+            const int Sout = Mq + C::pad(p + 1);
+            const int kstep = N / C::Np(p);
+            auto write = [&](const cf (&v)[16], int tau) {
+                const int Kin = tau / Mq, rr = tau - Kin * Mq;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const cf z = v[rev16(k)];
+                    lds[rr + Sout * (Kin + kstep * k)] = make_float2(z.x, z.y);
+                }
+            };
+            __builtin_amdgcn_wave_barrier();   // both of the lane's threads have read the layout entering pass p
+            write(va, taua);
+            write(vb, taub);
+        }
+    }
+}
+
+// HR rows (= waves) per step, 16 / HR steps per band, the band's rows leaving through KH = 8 / HR slices of km.
+template <int LOG2M, int HR>
+__global__ __launch_bounds__(64 * HR, 2) void row_pass_wave_kernel(
+    const float2* __restrict__ scratch, float* __restrict__ out, size_t n_frames, int A,
+    const float2* __restrict__ twM, float eps, int shift) {
+    using C = LdsCfg<LOG2M>;
+    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, WGT = 64 * HR, STEPS = 16 / HR, KH = 8 / HR, MK = M / KH;
+    static_assert(T == 128 && (HR == 4 || HR == 8), "one wave per row of 2048 points; 4 or 8 rows per step");
+    static_assert((size_t)MK * 17 * sizeof(float) <= (size_t)HR * C::SLOT * sizeof(float2), "transpose slice must fit the exchange area");
+    static_assert(LOG2M == 11, "W_N^64 below is written out for N = 2048");
+    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // Table entries of the lane's first thread only; those of its second thread, tau + 64, follow from them:
+    // W_N^(tau + 64 + T i) = W_N^(tau + T i) W_N^64, and the later passes' W_{N_p}^(tau % M_p) are the same for both
+    // (M_p divides 64) — ten registers less.  They are WAITED FOR here: a register still pending on the loop's entry edge
+    // makes the compiler put a vmcnt(0) in front of its first use inside the loop — in the middle of a transform, where
+    // it would wait for the previous band's stores.
+    LdsTw<LOG2M> twa;
+    lds_tw_init<LOG2M>(twa, twM, (int)threadIdx.x & 63);
+#pragma unroll
+    for (int i = 0; i < 16 / R0; ++i) asm volatile("" :: "v"(twa.w0[i].x), "v"(twa.w0[i].y));
+#pragma unroll
+    for (int i = 0; i < C::P; ++i) asm volatile("" :: "v"(twa.wp[i].x), "v"(twa.wp[i].y));
+    float2* __restrict__ lds = lds_all + (size_t)wave * C::SLOT;
+    const size_t nfft = (size_t)A * M;
+    const int bands = A / 16;
+    const size_t items = n_frames * (size_t)bands;
+    const int xor_q = shift ? 8 : 0;
+    for (size_t g = blockIdx.x; g < items; g += gridDim.x) {
+        const size_t f = g / bands;
+        const int k3_0 = (int)(g - f * bands) * 16;
+        const __amdgpu_buffer_rsrc_t ri = frame_rsrc(scratch + f * nfft + (size_t)k3_0 * M, (unsigned)(16 * M * 8));
+        float val[STEPS][2][16];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            // (the thread's coordinates are re-derived wherever they are used, from an opaque copy of its number: hoisted
+            // out of the persistent loop, the LDS / buffer offsets derived from them would be live across everything)
+            int tid_o = threadIdx.x;
+            asm volatile("" : "+v"(tid_o));
+            __builtin_assume(tid_o >= 0 && tid_o < WGT);
+            const int taua = tid_o & 63, taub = taua + 64;
+            cf va[16], vb[16];
+            const int ea = scratch_index(HR * st + wave, taua, M), eb = scratch_index(HR * st + wave, taub, M);
+#pragma unroll
+            for (int i = 0; i < C0; ++i)
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int u = scratch_index(0, (i + C0 * j) * T, M) * 8;
+                    const v2f xa = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, ea * 8, u, SDRK_SCR_LD_AUX));
+                    const v2f xb = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, eb * 8, u, SDRK_SCR_LD_AUX));
+                    va[i * R0 + j] = cf{xa.x, xa.y};
+                    vb[i * R0 + j] = cf{xb.x, xb.y};
+                }
+            LdsTw<LOG2M> twb = twa;
+            const cf w64 = cf{0.98078528040323044913f, -0.19509032201612826785f};   // W_2048^64 = exp(-i pi / 16)
+#pragma unroll
+            for (int i = 0; i < 16 / R0; ++i) twb.w0[i] = cmul(twa.w0[i], w64);
+            lds_fft_core_wave2<LOG2M>(va, vb, lds, taua, taub, twa, twb);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const cf za = va[rev16(q)], zb = vb[rev16(q)];
+                val[st][0][q] = logpsd_db(za.x, za.y, eps);
+                val[st][1][q] = logpsd_db(zb.x, zb.y, eps);
+            }
+        }
+        float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km - kh MK][17]
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            __syncthreads();  // the exchange area (or the previous slice of the tile) is free
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            __builtin_assume(tid >= 0 && tid < WGT);
+            {
+                const int taua = tid & 63, taub = taua + 64;
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int qq = q ^ xor_q;                          // km = tau + T qq; slice kh holds qq / (16 / KH) == kh
+                        if (qq / (16 / KH) == kh) {
+                            tile[(taua + T * (qq % (16 / KH))) * 17 + HR * st + wave] = val[st][0][q];
+                            tile[(taub + T * (qq % (16 / KH))) * 17 + HR * st + wave] = val[st][1][q];
+                        }
+                    }
+            }
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t ro = frame_rsrc(out + f * nfft + k3_0, (unsigned)((nfft - k3_0) * 4));
+            const int r = tid & 15, km0 = tid >> 4;                              // km = kh MK + km0 + (WGT / 16) i
+#pragma unroll 8
+            for (int i = 0; i < 16 * MK / WGT; ++i) {
+                const float x = tile[(km0 + (WGT / 16) * i) * 17 + r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), ro, ((kh * MK + km0) * A + r) * 4,
+                                                      i * (WGT / 16) * A * 4, SDRK_ROW_ST_AUX);
+            }
+        }
+        __syncthreads();  // tile reads done before the next band's exchanges
+    }
+}
+
 bool fft_tiled2_split(int nfft, int* log2a, int* log2m) {
     int lg = 0;
     while ((1 << lg) < nfft) ++lg;
@@ -600,6 +794,25 @@ static hipError_t launch_row_pair(const LaunchArgs& a, void* dst, size_t nf, int
     const size_t cap = (size_t)a.num_cus * per_cu;
     const unsigned grid = (unsigned)(items < cap ? items : cap);
     const float2* twM = static_cast<const float2*>(a.d_twiddle_2p) + 2048;
+    // M = 2048 with the log epilogue: one wave per row, two four-wave workgroups per CU (row_pass_wave_kernel above);
+    // SDRK_ROW_PAIR_2048 (A/B builds) keeps the one 1024-thread workgroup of row_pass_pair_kernel
+#ifndef SDRK_ROW_PAIR_2048
+    if constexpr (LOG2M == 11) {
+        if (a.epilogue == EPI_LOGPSD) {
+            constexpr int HR = 4;
+            const size_t lds_h = (size_t)HR * C::SLOT * sizeof(float2);
+            const size_t caph = (size_t)a.num_cus * (8 / HR);
+            const unsigned gh = (unsigned)(items < caph ? items : caph);
+            auto kernh = row_pass_wave_kernel<LOG2M, HR>;
+            static std::atomic<uint64_t> lds_ok_h{0};
+            hipError_t eh = ensure_dynamic_lds(reinterpret_cast<const void*>(kernh), lds_h, lds_ok_h);
+            if (eh != hipSuccess) return eh;
+            hipLaunchKernelGGL(kernh, dim3(gh), dim3(64 * HR), lds_h, a.stream, static_cast<const float2*>(a.d_scratch),
+                               static_cast<float*>(dst), nf, A, twM, a.eps, a.shift);
+            return hipGetLastError();
+        }
+    }
+#endif
 #define SDRK_ROWP(E)                                                                                             \
     do {                                                                                                         \
         auto kern = row_pass_pair_kernel<LOG2M, E>;                                                              \
