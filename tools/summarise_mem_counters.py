@@ -18,7 +18,7 @@ for line in txt.splitlines():
     if m and cur is not None:
         cur[m.group(1)] = float(m.group(4))
 print(txt.split("\n# one_config")[0].count("[pmc]") - 1, "rocprofv3 --pmc passes, one counter each (tools/pmc_mem_counters.sh); medians per dispatch\n")
-for name in ("col_pass_kernel", "row_pass_kernel", "col_pass_staged_kernel", "row_pass_pair_kernel"):
+for name in ("col_pass_kernel", "row_pass_kernel", "col_pass_staged_kernel", "row_pass_pair_kernel", "row_pass_wave_kernel"):
     c = kern.get(name)
     if not c:
         continue
