@@ -498,7 +498,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
 // In row_pass_pair_kernel<11> that marches all sixteen waves of the one 1024-thread workgroup a CU has room for through
 // load -> transform -> transpose -> store in lockstep: a wave parked at s_waitcnt / s_barrier 40 % of its cycles, VALU
 // 51 % of a SIMD, an L2 channel busy only 63 % of the dispatch — 70 us per 24-frame chunk where its bytes need 47
-// (profiles/r04/cfg5_sq_activity.txt, cfg5_mem_counters.txt).  Here each LANE is two of those 128 threads (tau = lane and
+// (profiles/r04/cfg5_pair_kernel_sq_activity.txt, cfg5_pair_kernel_mem_counters.txt).  Here each LANE is two of those 128 threads (tau = lane and
 // lane + 64: 32 points, 64 registers), so that
 //   * a row's exchanges stay inside one wave and need NO barrier: the wave's own LDS queue is the ordering;
 //   * a workgroup is four waves = four rows, 70 KiB of LDS, and TWO workgroups share a CU and overlap each other's
