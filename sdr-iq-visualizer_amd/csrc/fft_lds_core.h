@@ -159,6 +159,107 @@ __device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ l
     }
 }
 
+
+// TWO threads of the transform per lane (taua and taub = taua + T/2: 32 points in 64 registers), for frames whose T/2
+// lanes are ONE wave (T = 128: rows of 2048 points): the exchanges then need no barrier at all — the wave's own LDS queue is
+// the ordering, __builtin_amdgcn_wave_barrier() only keeps the compiler from moving LDS accesses across — and a kernel of
+// such waves runs at two per SIMD, 256 registers each (room for parked results).  The second thread's first-pass table
+// entries are W_N^(T/2) = W_32 times the first's and its later passes' entries coincide with the first's (M_p divides T/2):
+// nv2_tw_b.  (The same two-threads-per-lane form WITH workgroup barriers, for frames that span several waves — N = 8192 /
+// 16384 at 256 / 512 lanes with the next frame prefetched into the spare registers — was built and measured in round 4:
+// parity-green and 15 / 25 % SLOWER than the 512 / 1024-thread kernels, 0.340 against 0.296 and 0.44 against 0.352 ms per
+// 2^27 samples.  Half the waves hide half the latency; the barrier-free case is the one that pays.)
+__device__ __forceinline__ void nv2_sync() { __builtin_amdgcn_wave_barrier(); }
+
+template <int LOG2N>
+__device__ __forceinline__ LdsTw<LOG2N> nv2_tw_b(const LdsTw<LOG2N>& twa) {
+    LdsTw<LOG2N> twb = twa;
+    const cf w32 = cf{0.98078528040323044913f, -0.19509032201612826785f};   // W_N^(N/32) = exp(-i pi / 16)
+#pragma unroll
+    for (int i = 0; i < 16 / LdsCfg<LOG2N>::R0; ++i) twb.w0[i] = cmul(twa.w0[i], w32);
+    return twb;
+}
+
+template <int LOG2N>
+__device__ __forceinline__ void lds_fft_core_nv2(cf (&va)[16], cf (&vb)[16], float2* __restrict__ lds, int taua, int taub,
+                                                   const LdsTw<LOG2N>& twa, const LdsTw<LOG2N>& twb) {
+    using C = LdsCfg<LOG2N>;
+    constexpr int N = C::N, P = C::P, R0 = C::R0, T = C::T, C0 = 16 / R0;
+    static_assert(R0 != 16 && P > 1, "written for the R0 < 16 first pass (2048 = 8 x 16 x 16, 8192 = 2 x 16^3, 16384 = 4 x 16^3)");
+    auto first = [&](cf (&v)[16], const LdsTw<LOG2N>& tw) {
+#pragma unroll
+        for (int i = 0; i < C0; ++i) small_bfly<R0>(v, i * R0);
+#pragma unroll
+        for (int i = 0; i < C0; ++i) {
+            cf w1 = tw.w0[i], wk = w1;
+#pragma unroll
+            for (int k = 1; k < R0; ++k) {
+                v[i * R0 + k] = cmul(v[i * R0 + k], wk);
+                if (k + 1 < R0) wk = cmul(wk, w1);
+            }
+        }
+    };
+    first(va, twa);
+    first(vb, twb);
+    nv2_sync();
+    constexpr int S1 = C::Mp(0) + C::pad(1);
+    auto write1 = [&](const cf (&v)[16], int tau) {
+#pragma unroll
+        for (int i = 0; i < C0; ++i)
+#pragma unroll
+            for (int k = 0; k < R0; ++k) {
+                const cf z = v[i * R0 + k];
+                lds[(tau + T * i) + S1 * k] = make_float2(z.x, z.y);
+            }
+    };
+    write1(va, taua);
+    write1(vb, taub);
+#pragma unroll
+    for (int p = 1; p < P; ++p) {
+        const int Mq = C::Mp(p);
+        const int Sin = C::Mp(p - 1) + C::pad(p);
+        auto read = [&](cf (&v)[16], int tau) {
+            const int Kin = tau / Mq, rr = tau - Kin * Mq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 t = lds[rr + Mq * j + Sin * Kin];
+                v[j] = cf{t.x, t.y};
+            }
+        };
+        nv2_sync();                                // the layout entering pass p is complete
+        read(va, taua);
+        read(vb, taub);
+        radix16(va);
+        radix16(vb);
+        if (p < P - 1) {
+            auto twiddle = [&](cf (&v)[16], const LdsTw<LOG2N>& tw) {
+                cf w[16], w1 = tw.wp[p];
+                asm volatile("" : "+v"(w1.x), "+v"(w1.y));
+                pow_tree(w1, w);
+#pragma unroll
+                for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
+            };
+            twiddle(va, twa);
+            __builtin_amdgcn_sched_barrier(0);     // (one power tree at a time: interleaved, the two cost 32 more registers)
+            twiddle(vb, twb);
+            const int Sout = Mq + C::pad(p + 1);
+            const int kstep = N / C::Np(p);
+            auto write = [&](const cf (&v)[16], int tau) {
+                const int Kin = tau / Mq, rr = tau - Kin * Mq;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const cf z = v[rev16(k)];
+                    lds[rr + Sout * (Kin + kstep * k)] = make_float2(z.x, z.y);
+                }
+            };
+            nv2_sync();                            // both of the lane's threads have read the layout entering pass p
+            write(va, taua);
+            write(vb, taub);
+        }
+    }
+}
+
+
 // Scratch layout between the passes.  The col pass produces, per workgroup, all A values of k3 for W adjacent
 // m; the row pass consumes 16 adjacent k3 for all M values of m: whatever the layout, the two footprints meet
 // in 16 x 16 element squares.  Stored as [k3/16][m/16][k3%16][m%16] (2 KiB squares, row tiles contiguous)

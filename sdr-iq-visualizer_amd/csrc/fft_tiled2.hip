@@ -509,84 +509,6 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
 // Measured on config 5 (tools/ab_cfg.py, rocprofv3 kernel trace): 69.8 -> 57.6 us per chunk, N = 2^20 1.49 -> 1.40 ms;
 // N = 2^21 / 2^22 packed frames -3 ... -6 %.  Rows equal the pair kernel's to the last bits that the second thread's
 // derived table entries leave (W_N^(tau + 64 + T i) is formed as W_N^(tau + T i) W_N^64: one rounding).
-template <int LOG2N>
-__device__ __forceinline__ void lds_fft_core_wave2(cf (&va)[16], cf (&vb)[16], float2* __restrict__ lds, int taua, int taub,
-                                                   const LdsTw<LOG2N>& twa, const LdsTw<LOG2N>& twb) {
-    using C = LdsCfg<LOG2N>;
-    constexpr int N = C::N, P = C::P, R0 = C::R0, T = C::T, C0 = 16 / R0;
-    static_assert(R0 != 16 && P > 1, "written for the R0 < 16 first pass (M = 2048: 8 x 16 x 16)");
-    auto first = [&](cf (&v)[16], const LdsTw<LOG2N>& tw) {
-#pragma unroll
-        for (int i = 0; i < C0; ++i) small_bfly<R0>(v, i * R0);
-#pragma unroll
-        for (int i = 0; i < C0; ++i) {
-            cf w1 = tw.w0[i], wk = w1;
-#pragma unroll
-            for (int k = 1; k < R0; ++k) {
-                v[i * R0 + k] = cmul(v[i * R0 + k], wk);
-                if (k + 1 < R0) wk = cmul(wk, w1);
-            }
-        }
-    };
-    first(va, twa);
-    first(vb, twb);
-    constexpr int S1 = C::Mp(0) + C::pad(1);
-    auto write1 = [&](const cf (&v)[16], int tau) {
-#pragma unroll
-        for (int i = 0; i < C0; ++i)
-#pragma unroll
-            for (int k = 0; k < R0; ++k) {
-                const cf z = v[i * R0 + k];
-                lds[(tau + T * i) + S1 * k] = make_float2(z.x, z.y);
-            }
-    };
-    write1(va, taua);
-    write1(vb, taub);
-#pragma unroll
-    for (int p = 1; p < P; ++p) {
-        const int Mq = C::Mp(p);
-        const int Sin = C::Mp(p - 1) + C::pad(p);
-        auto read = [&](cf (&v)[16], int tau) {
-            const int Kin = tau / Mq, rr = tau - Kin * Mq;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float2 t = lds[rr + Mq * j + Sin * Kin];
-                v[j] = cf{t.x, t.y};
-            }
-        };
-        __builtin_amdgcn_wave_barrier();       // (scheduling only: the writes above precede the reads below in this wave's LDS queue)
-        read(va, taua);
-        read(vb, taub);
-        radix16(va);
-        radix16(vb);
-        if (p < P - 1) {
-            auto twiddle = [&](cf (&v)[16], const LdsTw<LOG2N>& tw) {
-                cf w[16], w1 = tw.wp[p];
-                asm volatile("" : "+v"(w1.x), "+v"(w1.y));
-                pow_tree(w1, w);
-#pragma unroll
-                for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
-            };
-            twiddle(va, twa);
-            __builtin_amdgcn_sched_barrier(0);     // (one power tree at a time: interleaved, the two cost 32 more registers)
-            twiddle(vb, twb);
-            const int Sout = Mq + C::pad(p + 1);
-            const int kstep = N / C::Np(p);
-            auto write = [&](const cf (&v)[16], int tau) {
-                const int Kin = tau / Mq, rr = tau - Kin * Mq;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const cf z = v[rev16(k)];
-                    lds[rr + Sout * (Kin + kstep * k)] = make_float2(z.x, z.y);
-                }
-            };
-            __builtin_amdgcn_wave_barrier();   // both of the lane's threads have read the layout entering pass p
-            write(va, taua);
-            write(vb, taub);
-        }
-    }
-}
-
 // HR rows (= waves) per step, 16 / HR steps per band, the band's rows leaving through KH = 8 / HR slices of km.
 template <int LOG2M, int HR>
 __global__ __launch_bounds__(64 * HR, 2) void row_pass_wave_kernel(
@@ -596,7 +518,6 @@ __global__ __launch_bounds__(64 * HR, 2) void row_pass_wave_kernel(
     constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, WGT = 64 * HR, STEPS = 16 / HR, KH = 8 / HR, MK = M / KH;
     static_assert(T == 128 && (HR == 4 || HR == 8), "one wave per row of 2048 points; 4 or 8 rows per step");
     static_assert((size_t)MK * 17 * sizeof(float) <= (size_t)HR * C::SLOT * sizeof(float2), "transpose slice must fit the exchange area");
-    static_assert(LOG2M == 11, "W_N^64 below is written out for N = 2048");
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // Table entries of the lane's first thread only; those of its second thread, tau + 64, follow from them:
@@ -640,11 +561,8 @@ __global__ __launch_bounds__(64 * HR, 2) void row_pass_wave_kernel(
                     va[i * R0 + j] = cf{xa.x, xa.y};
                     vb[i * R0 + j] = cf{xb.x, xb.y};
                 }
-            LdsTw<LOG2M> twb = twa;
-            const cf w64 = cf{0.98078528040323044913f, -0.19509032201612826785f};   // W_2048^64 = exp(-i pi / 16)
-#pragma unroll
-            for (int i = 0; i < 16 / R0; ++i) twb.w0[i] = cmul(twa.w0[i], w64);
-            lds_fft_core_wave2<LOG2M>(va, vb, lds, taua, taub, twa, twb);
+            const LdsTw<LOG2M> twb = nv2_tw_b<LOG2M>(twa);
+            lds_fft_core_nv2<LOG2M>(va, vb, lds, taua, taub, twa, twb);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf za = va[rev16(q)], zb = vb[rev16(q)];
