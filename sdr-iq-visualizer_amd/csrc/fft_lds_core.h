@@ -71,9 +71,13 @@ __device__ __forceinline__ void lds_tw_init(LdsTw<LOG2N>& tw, const float2* __re
 // operations only, then s_barrier — for callers that keep an LDS-DMA (`buffer_load ... lds`) in flight across the
 // transform into a DIFFERENT part of LDS: __syncthreads() would make hipcc wait vmcnt(0) at every barrier and
 // drain it.  The empty asm statements keep the compiler from moving LDS accesses across the barrier.
-template <bool RAW>
+// SYNC = 2: no barrier at all — for callers whose frame (its T threads) lies inside ONE wave (T <= 64, IL = 1 with a
+// per-frame base): the wave's own LDS queue orders its exchanges; only the compiler is kept from moving LDS accesses.
+template <int SYNC>
 __device__ __forceinline__ void lds_core_barrier() {
-    if (RAW) {
+    if (SYNC == 2) {
+        __builtin_amdgcn_wave_barrier();
+    } else if (SYNC == 1) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); vmcnt and expcnt untouched
         __builtin_amdgcn_s_barrier();
@@ -87,8 +91,8 @@ __device__ __forceinline__ void lds_core_barrier() {
 // (C0 = 16/R0); on return X[tau + T q] is in v[rev16(q)] (for P == 1, i.e. N == 16: X[k] in v[rev16(k)]).  LDS
 // element (inner address a) lives at lds[a * IL + off]: IL = 1 with a per-frame base for frame-per-thread-group
 // use, IL = W and off = column for W interleaved columns.  Contains 2 (P-1) workgroup barriers; the first also
-// protects the previous call's last reads.  RAW_BARRIER: see lds_core_barrier.
-template <int LOG2N, int IL, bool RAW_BARRIER = false>
+// protects the previous call's last reads.  SYNC: 0 = __syncthreads, 1 = raw s_barrier, 2 = none (see lds_core_barrier).
+template <int LOG2N, int IL, int SYNC = 0>
 __device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ lds, int off, int tau,
                                              const LdsTw<LOG2N>& tw) {
     using C = LdsCfg<LOG2N>;
@@ -118,7 +122,7 @@ __device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ l
                 }
             }
         }
-        lds_core_barrier<RAW_BARRIER>();  // previous transform's last-pass reads are done
+        lds_core_barrier<SYNC>();  // previous transform's last-pass reads are done
         constexpr int S1 = C::Mp(0) + C::pad(1);
 #pragma unroll
         for (int i = 0; i < C0; ++i)
@@ -127,7 +131,7 @@ __device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ l
                 const cf z = v[i * R0 + (R0 == 16 ? rev16(k) : k)];
                 lds[((tau + T * i) + S1 * k) * IL + off] = make_float2(z.x, z.y);
             }
-        lds_core_barrier<RAW_BARRIER>();
+        lds_core_barrier<SYNC>();
     }
 #pragma unroll
     for (int p = 1; p < P; ++p) {
@@ -146,7 +150,7 @@ __device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ l
             pow_tree(w1, w);
 #pragma unroll
             for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
-            lds_core_barrier<RAW_BARRIER>();  // everyone has read the layout entering pass p
+            lds_core_barrier<SYNC>();  // everyone has read the layout entering pass p
             const int Sout = Mq + C::pad(p + 1);
             const int kstep = N / C::Np(p);
 #pragma unroll
@@ -154,7 +158,7 @@ __device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ l
                 const cf z = v[rev16(k)];
                 lds[(rr + Sout * (Kin + kstep * k)) * IL + off] = make_float2(z.x, z.y);
             }
-            lds_core_barrier<RAW_BARRIER>();
+            lds_core_barrier<SYNC>();
         }
     }
 }

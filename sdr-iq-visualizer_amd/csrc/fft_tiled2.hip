@@ -33,6 +33,12 @@
 #ifndef SDRK_ROW_ST_AUX
 #define SDRK_ROW_ST_AUX 2    // dB rows: written once
 #endif
+// a row of M <= 1024 points is transformed by T = M / 16 <= 64 threads, i.e. inside one wave: its exchanges need no
+// workgroup barrier (SDRK_ROW_WAVE_SYNC=0 in A/B builds restores them)
+#ifndef SDRK_ROW_WAVE_SYNC
+#define SDRK_ROW_WAVE_SYNC 1
+#endif
+#define SDRK_ROW_SYNC(T) ((SDRK_ROW_WAVE_SYNC && (T) <= 64) ? 2 : 0)
 
 namespace sdrk {
 
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kerne
                 }
             lds_core_barrier<true>();                                      // every wave has picked its samples up
             dma(f + 1);
-            lds_fft_core<LOG2A, W, true>(v, xch, fr, tau, tw);
+            lds_fft_core<LOG2A, W, 1>(v, xch, fr, tau, tw);
             const __amdgpu_buffer_rsrc_t ro = frame_rsrc(scratch + f * nfft, (unsigned)(nfft * 8));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 51
                 const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, SDRK_SCR_LD_AUX));
                 v[i * R0 + j] = cf{x.x, x.y};
             }
-        lds_fft_core<LOG2M, 1>(v, lds, 0, rt, tw);
+        lds_fft_core<LOG2M, 1, SDRK_ROW_SYNC(T)>(v, lds, 0, rt, tw);
         __syncthreads();  // all rows are through their last LDS reads: the buffer becomes the transpose tile
         if (EPILOGUE == EPI_LOGPSD) {
             float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][ROWS + 1]
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
                     const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, (i + C0 * j) * T, M) * 8, SDRK_SCR_LD_AUX));
                     v[i * R0 + j] = cf{x.x, x.y};
                 }
-            lds_fft_core<LOG2M, 1>(v, lds, 0, rt, tw);
+            lds_fft_core<LOG2M, 1, SDRK_ROW_SYNC(T)>(v, lds, 0, rt, tw);
             if (EPILOGUE == EPI_LOGPSD) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
