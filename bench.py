@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1 << 20, help="frames per GPU (default 2^20)")
+    ap.add_argument("--first-frame", type=int, default=0,
+                    help="frame number of rank 0's first frame (rank g owns [first + g*F, first + (g+1)*F)); tests use it to put "
+                         "small runs past sample 2^32, where config 4's ranks 1..7 live")
     ap.add_argument("--window", default="hann", choices=["hann", "rect"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="budget for the single-core numpy cpu_baseline leg (0 disables both CPU legs)")
@@ -311,6 +314,17 @@ def _median(v):
     return float(statistics.median(v))
 
 
+def warm_up_by_time(fn, ms=100.0, at_least=3):
+    """Call fn() (a synchronous GPU step) until `ms` have passed: the shader clock of an idle MI355X sits near 1.0-1.4 GHz and
+    reaches its sustained 1.85-2.0 GHz only after tens of milliseconds of load (round 5: thirty N = 2^20 transforms from idle
+    take 1.53, 1.46, 1.46, 1.45, 1.42 ... 1.35 ms), so a leg that times its first few launches measures the ramp."""
+    t0, n = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < ms or n < at_least:
+        fn()
+        n += 1
+    return n
+
+
 def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, reps, scratch_candidates=6):
     """A device-resident run of one large-frame configuration: median launch time over `reps`, after the plan's
     scratch has been placed on this workload (sdrk_plan_tune_scratch; the probe times are reported)."""
@@ -325,7 +339,11 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
             with SpectrumPlan(nfft, window=window, device=dev) as plan:
                 plan.exec_device(d_gen.value, n_frames, d_out.value, frame_stride=stride)
                 plan.sync()
-                probe, chosen = plan.tune_scratch(d_gen.value, n_frames, d_out.value, scratch_candidates, frame_stride=stride)
+                probe, chosen, report = [], 0, None
+                if scratch_candidates > 1:
+                    probe, chosen = plan.tune_scratch(d_gen.value, n_frames, d_out.value, scratch_candidates, frame_stride=stride)
+                    report = plan.last_placement
+                warm_up_by_time(lambda: plan.exec_device_timed(d_gen.value, n_frames, d_out.value, 1, frame_stride=stride))
                 ms = plan.exec_device_timed_each(d_gen.value, n_frames, d_out.value, reps, frame_stride=stride)
         finally:
             lib.sdrk_dev_free(dev, d_out)
@@ -339,15 +357,22 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
             "frame_Msamples_per_s": round(n_frames * nfft / t / 1e6, 1),
             "algorithmic_bytes": algo, "algorithmic_formula": "8*L + 4*rows*N",
             "GBps": round(algo / t / 1e9, 1), "frac": round(algo / t / 1e9 / HBM_PEAK_GBPS, 4),
-            "scratch_placement": {"probe_ms": [round(v, 3) for v in probe], "chosen": chosen,
-                                  "what": "sdrk_plan_tune_scratch: the plan's transform timed with its own and five freshly "
-                                          "allocated scratch buffers, fastest kept (index 0 = untuned)"}}
+            "warmup": "the plan's own transform for >= 100 ms before the timed launches (an idle device needs tens of ms of load "
+                      "to reach its sustained shader clock: tools/cfg_steady.py)",
+            "scratch_placement": None if report is None else {
+                "probe_ms": [round(v, 3) for v in probe], "chosen": chosen, **report,
+                "what": "sdrk_plan_tune_scratch: warm-up by time, the plan's transform timed with its own scratch (index 0) and with "
+                        "freshly allocated ones, index 0 timed AGAIN after the last; a candidate replaces the present scratch only "
+                        "if it beats both timings of it by 1 %; gain_vs_retimed_first = 1 - chosen / re-timed first"}}
 
 
-def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=16, px=4096):
+def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=24, px=4096):
     """BASELINE.json configs[4] as SURVEY.md §8(d) words it, one channel on this GPU: back-to-back N = 2^20 Hann
     frames from a device-resident stream, every row appended to the device waterfall ring (100 x 4 MiB), and after
-    each batch of rows a decimated (max-hold to `px` bins) read-out of the new rows to the host."""
+    each batch of rows a decimated (max-hold to `px` bins) read-out of the new rows to the host.  `batch` = the 24 frames of
+    one scratch chunk (192 MiB / 8 MiB), so a batch is one col-pass and one row-pass launch (two where the ring wraps); the row
+    pass leaves every row max-hold-decimated by 16 beside the ring, and the read-out reduces those (4 MiB per 16 rows) instead
+    of reading the 4 MiB rows again."""
     import numpy as np
     nfft = 1 << 20
     d_in = ctypes.c_void_p()
@@ -360,10 +385,11 @@ def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=16, p
                 wf.clear()
                 got = 0
                 for f0 in range(0, n_frames, batch):
+                    nb = min(batch, n_frames - f0)
                     _ffi.check(lib.sdrk_waterfall_append_iq_device(wf._h(), plan.handle,
                                                                   ctypes.c_void_p(d_in.value + f0 * nfft * 8),
-                                                                  ctypes.c_size_t(batch), ctypes.c_size_t(nfft)))
-                    got += wf.as_array(max_rows=batch, decimate=nfft // px).shape[0]
+                                                                  ctypes.c_size_t(nb), ctypes.c_size_t(nfft)))
+                    got += wf.as_array(max_rows=nb, decimate=nfft // px).shape[0]
                 return got
 
             slots = [pkg.pinned_empty((batch, px), np.float32) for _ in range(2)]
@@ -374,32 +400,50 @@ def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=16, p
                 wf.clear()
                 got, pending = 0, False
                 for i, f0 in enumerate(range(0, n_frames, batch)):
-                    wf.append_iq_device(d_in.value + f0 * nfft * 8, batch, nfft, wait=False)
+                    nb = min(batch, n_frames - f0)
+                    wf.append_iq_device(d_in.value + f0 * nfft * 8, nb, nfft, wait=False)
                     if pending:
                         got += wf.gather_end().shape[0]
-                    wf.gather_begin(max_rows=batch, decimate=nfft // px, out=slots[i & 1])
+                    wf.gather_begin(max_rows=nb, decimate=nfft // px, out=slots[i & 1])
                     pending = True
                 got += wf.gather_end().shape[0]
                 return got
 
-            run()
+            warm_up_by_time(run)
             ts = []
-            for _ in range(5):
+            for _ in range(7):
                 t0 = time.perf_counter()
                 rows = run()
                 ts.append(time.perf_counter() - t0)
-            run_pipelined()
+            warm_up_by_time(run_pipelined, ms=30.0)
             tp = []
-            for _ in range(5):
+            for _ in range(7):
                 t0 = time.perf_counter()
                 rows_p = run_pipelined()
                 tp.append(time.perf_counter() - t0)
+            companions = wf.maxhold16_rows()
+            # the ring's newest row bit for bit what the plain transform gives, and the decimated rows what numpy makes of the ring's
+            check_rows = wf.as_array(max_rows=2)
+            d_chk = ctypes.c_void_p()
+            _ffi.check(lib.sdrk_dev_alloc(dev, 2 * nfft * 4, ctypes.byref(d_chk)))
+            try:
+                plan.exec_device(d_in.value + (n_frames - 2) * nfft * 8, 2, d_chk.value)
+                plan.sync()
+                plain = np.empty((2, nfft), dtype=np.float32)
+                _ffi.check(lib.sdrk_memcpy_d2h(dev, plain.ctypes.data_as(ctypes.c_void_p), d_chk, plain.nbytes))
+            finally:
+                lib.sdrk_dev_free(dev, d_chk)
+            ring_equals_transform = bool(np.array_equal(check_rows, plain))
+            decimated_equals_numpy = bool(np.array_equal(wf.as_array(max_rows=2, decimate=nfft // px),
+                                                         check_rows.reshape(2, px, nfft // px).max(-1)))
     finally:
         wf.close()
         lib.sdrk_dev_free(dev, d_in)
     t = _median(ts)
     rate = n_frames * nfft / t / 1e6
     return {"nfft": nfft, "frames": n_frames, "window": "hann", "ring_rows": 100, "gather": f"every {batch} rows, max-hold to {px} bins, D2H",
+            "ring_rows_with_maxhold16_companion": companions, "ring_rows_equal_plain_transform": ring_equals_transform,
+            "decimated_rows_equal_numpy_max_of_ring_rows": decimated_equals_numpy,
             "rows_gathered": rows, "ms": round(t * 1e3, 3), "ms_min": round(min(ts) * 1e3, 3), "ms_max": round(max(ts) * 1e3, 3),
             "Msamples_per_s": round(rate, 1), "realtime_factor_at_61.44_Msps": round(rate / 61.44, 1),
             "realtime_61.44_Msps_holds": bool(rate >= 61.44),
@@ -633,7 +677,8 @@ def child_command(args, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--frames", str(args.frames), "--window", args.window, "--parity-frames", str(args.parity_frames),
+           "--frames", str(args.frames), "--first-frame", str(args.first_frame), "--window", args.window,
+           "--parity-frames", str(args.parity_frames),
            "--placement-candidates", str(args.placement_candidates), "--cpu-seconds", "0"]
     if args.no_secondary:
         cmd.append("--no-secondary")
@@ -720,9 +765,12 @@ def main():
     # One rank per GPU over RCCL ("nccl").  Rehearsal on a box with fewer GPUs than ranks
     # (ranks then share a device, which RCCL refuses): gloo carries the barrier/max-reduce.
     backend = "nccl" if n_dev >= world else "gloo"
+    backend_note, grp = None, None
     if n_dev < world:
         args.placement_candidates = 1               # ranks share a GPU here: no probing with its memory
-    backend_note, grp = None, None
+        backend_note = (f"{world} ranks on {n_dev} visible GPU(s): RCCL does not form a communicator over ranks that share a "
+                        "device, so the barrier and the reductions of the times run over gloo (a rehearsal of the control path, "
+                        "not a scaling measurement)")
     if "RANK" in os.environ:
         import datetime
         import torch.distributed as dist
@@ -760,7 +808,7 @@ def main():
     tel = Telemetry(info) if rank == 0 else None
 
     frames = args.frames
-    first_frame = rank * frames                     # config 4: GPU g owns [g*F, (g+1)*F)
+    first_frame = args.first_frame + rank * frames  # config 4: GPU g owns [g*F, (g+1)*F)
     plan = SpectrumPlan(NFFT, window=None if args.window == "rect" else args.window, device=dev)
 
     # the resident IQ / row buffers, the rows placed by sdrk_dev_alloc_stream_pair (the streaming rate of a
@@ -771,10 +819,12 @@ def main():
     _ffi.check(lib.sdrk_dev_alloc_stream_pair(dev, frames * NFFT * 8, frames * NFFT * 4, args.placement_candidates,
                                               plan.handle, ctypes.byref(d_in), ctypes.byref(d_out), probe_ms,
                                               ctypes.byref(chosen)))
+    from sdr_iq_visualizer_amd.spectrum import placement_report
     placement = {"candidates": args.placement_candidates, "probe_ms": [round(float(v), 4) for v in probe_ms],
-                 "chosen": int(chosen.value),
+                 "chosen": int(chosen.value), **placement_report(),
                  "what": "output buffer chosen among candidates by timing the plan's transform over each pairing with "
-                         "the input buffer (sdrk_dev_alloc_stream_pair); 1 candidate = plain allocation"}
+                         "the input buffer (sdrk_dev_alloc_stream_pair: warm-up by time, candidate 0 timed again after the "
+                         "last one — retimed_first_ms — and counted with the better of its two timings); 1 candidate = plain allocation"}
     _ffi.check(lib.sdrk_synth_fill(dev, 1234, first_frame, frames, NFFT, d_in, None))
 
     def barrier():
@@ -825,9 +875,13 @@ def main():
             parity = max(parity, float(np.abs(mg - mr).max() / mr.max()))
         n_checked = int(picks.size)
     if dist is not None:
-        t = torch.tensor([parity], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
-        parity = float(t[0])
+        mine = torch.tensor([parity, float(first_frame), float(first_frame + frames)], device=red_dev, dtype=torch.float64)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine, group=grp)
+        per_rank["parity_max_rel_err"] = [float(v[0]) for v in everyone]
+        per_rank["frame_range"] = [[int(v[1]), int(v[2])] for v in everyone]     # rank g: [first + g F, first + (g + 1) F)
+        per_rank["first_sample_index"] = [int(v[1]) * NFFT for v in everyone]     # >= 2^32 from config 4's rank 1 on: 64-bit frame numbers in the generator
+        parity = max(per_rank["parity_max_rel_err"])
 
     # the same bytes with no arithmetic, same buffers, same process: the measured-copy ceiling (rank 0)
     copy_gbps = None
@@ -851,6 +905,28 @@ def main():
             copy11_gbps = 2 * nbytes / (_median(list(ms)) * 1e-3) / 1e9
         except Exception as e:
             print(f"[bench] 1:1 copy probe failed: {e}", file=sys.stderr)
+
+    # ... and the same 1:1 copy on a small pair (4 + 2 GiB) allocated beside the resident one, same process: the footprint
+    # dependence of the copy ceiling on record (the guide's 6.29 TB/s is a small-footprint figure)
+    copy11_small = None
+    if solo and not args.no_secondary and frames * NFFT * 8 >= (8 << 30):
+        try:
+            a_s, b_s = ctypes.c_void_p(), ctypes.c_void_p()
+            _ffi.check(lib.sdrk_dev_alloc(dev, 4 << 30, ctypes.byref(a_s)))
+            try:
+                _ffi.check(lib.sdrk_dev_alloc(dev, 2 << 30, ctypes.byref(b_s)))
+                try:
+                    ms = (ctypes.c_float * 20)()
+                    _ffi.check(lib.sdrk_copy_probe(dev, a_s, b_s, 2 << 30, 20, ms))
+                    copy11_small = {"GBps": round(2 * (2 << 30) / (_median(list(ms)) * 1e-3) / 1e9, 1),
+                                    "what": "sdrk_copy_probe on a fresh 4 GiB + 2 GiB pair (2 GiB copied), same process, the "
+                                            "32 + 16 GiB pair still allocated"}
+                finally:
+                    lib.sdrk_dev_free(dev, b_s)
+            finally:
+                lib.sdrk_dev_free(dev, a_s)
+        except Exception as e:
+            print(f"[bench] small-footprint copy probe failed: {e}", file=sys.stderr)
 
     # the other window of configs[1] on the same buffers (SURVEY.md §8d names Hann and rect); rank 0, N = 1 only
     other_window = None
@@ -887,14 +963,14 @@ def main():
                 r["cpu_baseline"] = cpu_large["config3"]
                 r["gpu_over_one_core"] = round(r["frame_Msamples_per_s"] / cpu_large["config3"]["value"], 1)
             secondary["config3"] = r
-            r = device_config(lib, _ffi, SpectrumPlan, dev, 1 << 20, 256, 1 << 20, "hann", 7)
+            r = device_config(lib, _ffi, SpectrumPlan, dev, 1 << 20, 256, 1 << 20, "hann", 15)
             r["workload"] = "BASELINE.json configs[4], one channel: 256 back-to-back N=2^20 frames"
             r["realtime_factor_at_61.44_Msps"] = round((256 * (1 << 20) / 61.44e6) / (r["ms"] * 1e-3), 1)
             if cpu_large:
                 r["cpu_baseline"] = cpu_large["config5"]
                 r["gpu_over_one_core"] = round(r["frame_Msamples_per_s"] / cpu_large["config5"]["value"], 1)
             secondary["config5_one_channel"] = r
-            r = device_config(lib, _ffi, SpectrumPlan, dev, 1 << 20, 256, 1 << 20, None, 7, scratch_candidates=3)
+            r = device_config(lib, _ffi, SpectrumPlan, dev, 1 << 20, 256, 1 << 20, None, 15, scratch_candidates=1)
             r["workload"] = "BASELINE.json configs[4], one channel, rectangular window (SURVEY.md 8d: rect and Hann)"
             r["realtime_factor_at_61.44_Msps"] = round((256 * (1 << 20) / 61.44e6) / (r["ms"] * 1e-3), 1)
             secondary["config5_one_channel_rect"] = r
@@ -915,12 +991,13 @@ def main():
             torch.cuda.synchronize()
             dist.barrier(group=grp, **({"device_ids": [dev]} if backend == "nccl" else {}))
 
+        rank_barrier()
         try:
-            rank_barrier()
             rec = channel_config5(lib, _ffi, pkg, SpectrumPlan, dev)
-            rank_barrier()
         except Exception as e:                                   # noqa: BLE001 - a secondary leg never costs the line
             rec = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            rank_barrier()                                       # every rank issues the same sequence of collectives, whatever its leg did
         everyone = [None] * world
         dist.all_gather_object(everyone, rec)                    # the default (gloo) group: plain Python objects
         if rank == 0:
@@ -935,6 +1012,8 @@ def main():
                 "aggregate_Msamples_per_s": round(sum(r["pipelined"]["Msamples_per_s"] for r in ok), 1),
                 "realtime_61.44_Msps_holds_on_every_channel": bool(ok) and len(ok) == world and
                                                               all(r["pipelined"]["Msamples_per_s"] >= 61.44 for r in ok),
+                "checks": {k: [bool(r.get(k)) if r else False for r in everyone]
+                           for k in ("ring_rows_equal_plain_transform", "decimated_rows_equal_numpy_max_of_ring_rows")},
                 "errors": [r["error"] for r in everyone if r and "error" in r] or None}}
 
     if rank == 0:
@@ -996,6 +1075,7 @@ def main():
                 "frac_of_copy_1to1": None if not copy11_gbps else round(achieved / copy11_gbps, 4),
                 "copy_1to1_what": "sdrk_copy_probe: plain 1:1 copy, 16 B per lane each way, first half of the IQ buffer into "
                                   "the row buffer (read + written bytes / time); MI355X_MICROARCH.md quotes 6.29 TB/s for this shape",
+                "copy_1to1_small_footprint": copy11_small,
             },
             "launch_ms": {"min": round(min(each_ms), 4), "median": round(_median(each_ms), 4),
                           "max": round(max(each_ms), 4), "mean": round(sum(each_ms) / len(each_ms), 4),

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SDRK_VERSION 400 /* 0.4.0: every addition to this ABI bumps it; _ffi.py refuses a library of another version */
+#define SDRK_VERSION 500 /* 0.5.0: every addition to this ABI bumps it; _ffi.py refuses a library of another version */
 
 typedef enum sdrk_status {
     SDRK_OK = 0,
@@ -82,7 +82,8 @@ int sdrk_dev_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
  * two allocations are paired — read-only and (with rare exceptions) write-only rates do not depend on the buffer, and the level is
  * stable for the life of the pair (csrc/tools/placeprobe.hip).  This call allocates the input,
  * then up to `candidates` outputs (earlier ones stay allocated meanwhile, so each lands elsewhere), times a
- * probe over each pairing and keeps the fastest.  The probe is `plan`'s own transform over the pair (packed
+ * probe over each pairing (after a warm-up by time; candidate 0 is timed again at the end and counts with the better of
+ * its two timings: sdrk_placement_report) and keeps the fastest.  The probe is `plan`'s own transform over the pair (packed
  * frames; the input need not be initialised) or, with plan = NULL, a no-arithmetic kernel with the 2:1 traffic
  * shape.  probe_ms (may be NULL): `candidates` floats, the median probe time of each candidate (0 = not tried);
  * chosen (may be NULL): index kept.  Pairs too small for the effect to show (< 2^13 frame-equivalents of 4096
@@ -148,9 +149,19 @@ int sdrk_plan_staging_probe(const sdrk_plan* plan, float* probe_ms, int capacity
  * frame_stride) -> d_out_db with the present scratch and with up to `candidates` - 1 freshly allocated ones,
  * keeps the fastest and frees the others.  probe_ms (or NULL) receives `candidates` times (0 = not tried);
  * chosen (or NULL) the index kept (0 = the original).  d_out_db is overwritten with the transform's result.
- * Plans without a scratch return at once.  Not to be called while the plan is in use by another thread. */
+ * Plans without a scratch return at once.  Not to be called while the plan is in use by another thread.
+ * The probe warms up by time first (>= 60 ms of the plan's own launches: an idle MI355X needs tens of milliseconds of load
+ * to reach its sustained shader clock, and a probe that starts cold measures that ramp instead of the placement), times
+ * candidate 0 AGAIN after the last candidate, and replaces the present scratch only by a candidate that beats both of its
+ * timings by one per cent (sdrk_placement_report has the re-timed figure). */
 int sdrk_plan_tune_scratch(sdrk_plan* plan, const void* d_iq_c64, size_t n_frames, size_t frame_stride_samples,
                            float* d_out_db, int candidates, float* probe_ms, int* chosen);
+/* What the LAST placement probe on the calling thread did (sdrk_dev_alloc_stream_pair, sdrk_plan_tune_scratch): the wall
+ * time and number of its warm-up launches, candidate 0 as first timed and as timed again after the last candidate, and the
+ * kept candidate's time, all in milliseconds (any pointer may be NULL).  Returns the number of candidates it tried (0: no
+ * probe has run on this thread, or the last one had nothing to place).  A first / re-timed pair that differs by more than
+ * the candidates do says the probe measured drift, not placement. */
+int sdrk_placement_report(float* warm_ms, int* warm_launches, float* first_ms, float* retimed_first_ms, float* chosen_ms);
 int sdrk_plan_destroy(sdrk_plan* plan);
 int sdrk_plan_nfft(const sdrk_plan* plan);
 int sdrk_plan_device(const sdrk_plan* plan);
@@ -350,6 +361,12 @@ int sdrk_waterfall_read(sdrk_waterfall* wf, float* out, size_t max_rows, size_t*
  * dashboard/callbacks.py:182-190, which is unusable at nfft = 2^20.) */
 int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
                                   size_t* n_rows);
+/* For nfft = 2^20 ... 2^22 the transform behind sdrk_waterfall_append_iq* also leaves every row max-hold-decimated by 16
+ * beside the ring (1/16 of its size; the row pass has the sixteen neighbouring bins in LDS anyway), and a max-mode read-out
+ * whose factor is a multiple of 16 is served from those — it reads 1/16 of the bytes instead of every 4 MiB row again, with
+ * bit-identical results (a maximum does not depend on the order).  Rows appended as finished rows carry no such companion;
+ * a read-out that touches one falls back to the full rows.  Returns how many of the valid rows carry one. */
+int sdrk_waterfall_maxhold16_rows(const sdrk_waterfall* wf);
 /* sdrk_waterfall_read_decimated in two halves, for a continuous channel (BASELINE config 5): _begin enqueues the
  * reduction behind everything appended so far and the device-to-host copy of its result on a second stream, and
  * returns; _end waits for that copy.  Between the two the caller can enqueue the next batch of frames

@@ -30,7 +30,7 @@ WINDOW_HANN = 1
 WINDOW_CUSTOM = 2
 
 MAX_LOG2_NFFT = 22
-ABI_VERSION = 400                 # SDRK_VERSION of include/sdrk.h this binding was written against
+ABI_VERSION = 500                 # SDRK_VERSION of include/sdrk.h this binding was written against
 FEAT_PLANES = 19                  # SDRK_FEAT_* plane numbers of include/sdrk.h
 (FEAT_MAX_DB, FEAT_NOISE_FLOOR_DB, FEAT_SNR_DB, FEAT_FLATNESS, FEAT_KURTOSIS, FEAT_THRESHOLD_DB, FEAT_PEAK_SPACING_STD_HZ,
  FEAT_PEAK_DENSITY, FEAT_BANDWIDTH_HZ) = range(9)
@@ -73,6 +73,7 @@ SYMBOLS = [
     ("sdrk_plan_staging_probe", c_int, [c_void_p, POINTER(c_float), c_int, POINTER(c_int)]),
     ("sdrk_plan_tune_scratch", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float),
                                        POINTER(c_int)]),
+    ("sdrk_placement_report", c_int, [POINTER(c_float), POINTER(c_int), POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
     ("sdrk_plan_destroy", c_int, [c_void_p]),
     ("sdrk_plan_nfft", c_int, [c_void_p]),
     ("sdrk_plan_device", c_int, [c_void_p]),
@@ -119,6 +120,7 @@ SYMBOLS = [
     ("sdrk_waterfall_rows", c_int, [c_void_p]),
     ("sdrk_waterfall_read", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]),
     ("sdrk_waterfall_read_decimated", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, POINTER(c_size_t)]),
+    ("sdrk_waterfall_maxhold16_rows", c_int, [c_void_p]),
     ("sdrk_waterfall_clear", c_int, [c_void_p]),
 ]
 

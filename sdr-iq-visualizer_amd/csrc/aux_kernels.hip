@@ -110,6 +110,38 @@ hipError_t launch_decimate_rows(const float* d_ring, int nfft, int maxlen, int s
     return hipGetLastError();
 }
 
+// Max-hold read-out from the by-16 rows that the M = 2048 row pass writes beside the ring (fft_tiled2.hip,
+// row_pass_wave_kernel<…, MIP>): mip[slot][band][km] = max of output bins [16 (bands km + band), + 16), bands = A / 16 =
+// nfft / 16 / 2048.  out[r][b] = max over by-16 index j in [b G, (b + 1) G), G = factor / 16, j = bands km + band.  One
+// thread per output bin; neighbouring lanes read neighbouring km of the same band.  Max is exact, so the result is
+// bit-identical to decimate_rows_kernel's over the full rows.
+__global__ __launch_bounds__(256) void decimate_mip_kernel(const float* __restrict__ mip, int n16, int bands, int maxlen,
+                                                           int start_slot, int n_rows, int G, float* __restrict__ out) {
+    const int bins = n16 / G, M = n16 / bands;
+    const size_t total = (size_t)n_rows * bins;
+    for (size_t item = (size_t)blockIdx.x * 256 + threadIdx.x; item < total; item += (size_t)gridDim.x * 256) {
+        const int r = (int)(item / bins), b = (int)(item - (size_t)r * bins);
+        const float* __restrict__ src = mip + (size_t)((start_slot + r) % maxlen) * n16;
+        float acc = -INFINITY;
+        for (int i = 0; i < G; ++i) {
+            const int j = b * G + i, km = j / bands, band = j - km * bands;
+            acc = fmaxf(acc, src[(size_t)band * M + km]);
+        }
+        out[item] = acc;
+    }
+}
+
+hipError_t launch_decimate_mip(const float* d_mip_ring, int nfft, int maxlen, int start_slot, int n_rows, int factor,
+                               float* d_out, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    const int n16 = nfft / 16, G = factor / 16, bands = n16 / 2048;
+    size_t blocks = ((size_t)n_rows * (n16 / G) + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(decimate_mip_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_mip_ring, n16, bands, maxlen,
+                       start_slot, n_rows, G, d_out);
+    return hipGetLastError();
+}
+
 // Streaming-copy ceiling with the spectrum path's traffic shape and nothing else: per 4096-sample
 // frame 32 KiB read (8 x 16 B per thread), 16 KiB written (4 x 16 B per thread), no arithmetic beyond one
 // add per output vector, non-temporal both ways, frames interleaved over a persistent grid of

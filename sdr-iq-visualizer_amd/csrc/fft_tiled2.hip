@@ -131,7 +131,10 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
     if (FIXED) {
         // tile position t = blockIdx % tiles; the gridDim / tiles workgroups of one position split the frames
         // into contiguous runs
-        const int m = (int)(blockIdx.x % tiles) * W + fr;
+        // W == 8: positions p and p + 8 (workgroups b and b + 8: the same XCD under the round-robin placement) share
+        // the 128-byte lines of input and scratch
+        const int p = (int)(blockIdx.x % tiles);
+        const int m = ((W == 8 && (tiles & 15) == 0) ? (p & ~15) + ((p & 7) << 1) + ((p >> 3) & 1) : p) * W + fr;
         const size_t lanes = gridDim.x / tiles, lane = blockIdx.x / tiles;
         const size_t run = (n_frames + lanes - 1) / lanes;
         const size_t f_begin = lane * run, f_end = f_begin + run < n_frames ? f_begin + run : n_frames;
@@ -328,9 +331,24 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kerne
 #ifndef SDRK_COL_W256
 #define SDRK_COL_W256 16
 #endif
+// A = 512 (N = 2^18 ... 2^20): SDRK_STAGED_W9 columns through col_pass_staged_kernel (16: one 512-thread workgroup per
+// CU; 8: two 256-thread workgroups per CU), or, with SDRK_STAGED_W9 = 0, SDRK_COL_W9 columns through col_pass_kernel
+// (8: software-pipelined 256-thread workgroups, three per CU)
+#ifndef SDRK_STAGED_W9
+#define SDRK_STAGED_W9 16
+#endif
+#ifndef SDRK_COL_W9
+#define SDRK_COL_W9 16
+#endif
 // columns per col-pass tile; A = 512 and A = 1024 take col_pass_staged_kernel with STAGED_W columns
-#define STAGED_W(LOG2A) ((LOG2A) == 10 ? 8 : ((LOG2A) == 9 ? 16 : 0))
-#define COL_TILE_W(LOG2A) (STAGED_W(LOG2A) ? STAGED_W(LOG2A) : ((LOG2A) == 11 ? 8 : ((LOG2A) == 8 ? SDRK_COL_W256 : 16)))
+#define STAGED_W(LOG2A) ((LOG2A) == 10 ? 8 : ((LOG2A) == 9 ? SDRK_STAGED_W9 : 0))
+#define COL_TILE_W(LOG2A) (STAGED_W(LOG2A) ? STAGED_W(LOG2A) : ((LOG2A) == 11 ? 8 : ((LOG2A) == 8 ? SDRK_COL_W256 : ((LOG2A) == 9 ? SDRK_COL_W9 : 16))))
+// the software-pipelined (FIXED) form of col_pass_kernel: workgroups of <= 256 threads, whole lines (16 columns) or paired half lines
+__host__ __device__ constexpr bool col_can_fix(int T, int W) { return T * W <= 256 && (W >= 16 || (W == 8 && T == 32)); }
+// workgroups of col_pass_staged_kernel per CU: LDS = exchange area + staging buffer
+__host__ __device__ constexpr int staged_per_cu(int SLOT, int A, int W) {
+    return (size_t)2 * ((size_t)SLOT * W + (size_t)A * W) * 8 <= 160 * 1024 ? 2 : 1;
+}
 
 // row pass for M = 256 and 512: tile = 16 adjacent k3 rows x M (34.8 / 69.6 KiB of LDS: four / two workgroups per
 // CU, which overlap each other's load, transform and store phases).
@@ -516,10 +534,14 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
 // N = 2^21 / 2^22 packed frames -3 ... -6 %.  Rows equal the pair kernel's to the last bits that the second thread's
 // derived table entries leave (W_N^(tau + 64 + T i) is formed as W_N^(tau + T i) W_N^64: one rounding).
 // HR rows (= waves) per step, 16 / HR steps per band, the band's rows leaving through KH = 8 / HR slices of km.
-template <int LOG2M, int HR>
+// MIP: besides the rows, write each band's max over its 16 rows per km — 16 CONSECUTIVE bins of the output row, since
+// k = A km + k3 — i.e. the row max-hold-decimated by 16, as mip[frame][band = k3 / 16][km (shifted like the row)]: N / 16
+// floats per frame, 8 KiB contiguous per band.  The waterfall's decimated read-out (sdrk_waterfall_read_decimated, any
+// factor that is a multiple of 16) then reads 1/16 of the bytes instead of every 4 MiB row again.
+template <int LOG2M, int HR, bool MIP>
 __global__ __launch_bounds__(64 * HR, 2) void row_pass_wave_kernel(
     const float2* __restrict__ scratch, float* __restrict__ out, size_t n_frames, int A,
-    const float2* __restrict__ twM, float eps, int shift) {
+    const float2* __restrict__ twM, float eps, int shift, float* __restrict__ mip) {
     using C = LdsCfg<LOG2M>;
     constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, WGT = 64 * HR, STEPS = 16 / HR, KH = 8 / HR, MK = M / KH;
     static_assert(T == 128 && (HR == 4 || HR == 8), "one wave per row of 2048 points; 4 or 8 rows per step");
@@ -576,6 +598,36 @@ __global__ __launch_bounds__(64 * HR, 2) void row_pass_wave_kernel(
                 val[st][1][q] = logpsd_db(zb.x, zb.y, eps);
             }
         }
+        if (MIP) {
+            // partial maxima of this wave's STEPS rows, one float per (thread of the transform, q): part[wave][j = 16 h + q][lane]
+            static_assert((size_t)HR * 32 * 64 * sizeof(float) <= (size_t)HR * C::SLOT * sizeof(float2), "partial maxima must fit the exchange area");
+            float* __restrict__ part = reinterpret_cast<float*>(lds_all);
+            __syncthreads();  // every wave is through its last exchange reads
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            __builtin_assume(tid >= 0 && tid < WGT);
+            const int lane = tid & 63;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float m = val[0][h][q];
+#pragma unroll
+                    for (int st = 1; st < STEPS; ++st) m = fmaxf(m, val[st][h][q]);
+                    part[(wave * 32 + 16 * h + q) * 64 + lane] = m;
+                }
+            __syncthreads();
+            float* __restrict__ mrow = mip + (f * bands + (size_t)(k3_0 >> 4)) * M;
+#pragma unroll
+            for (int i = 0; i < 2048 / WGT; ++i) {
+                const int s = tid + WGT * i, j = s >> 6;                       // j = 16 h + q (uniform per wave), lane = s & 63
+                float m = part[j * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < HR; ++w) m = fmaxf(m, part[(w * 32 + j) * 64 + lane]);
+                const int km = lane + 64 * (j >> 4) + T * ((j & 15) ^ xor_q);   // tau + T (q ^ xor_q), tau = lane + 64 h
+                mrow[km] = m;
+            }
+        }
         float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km - kh MK][17]
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
@@ -610,6 +662,15 @@ __global__ __launch_bounds__(64 * HR, 2) void row_pass_wave_kernel(
     }
 }
 
+// frame lengths whose row pass (row_pass_wave_kernel: M = 2048, log epilogue) can also write the max-hold-by-16 rows
+bool fft_tiled2_has_mip(int nfft, int epilogue) {
+#ifdef SDRK_ROW_PAIR_2048
+    return false;
+#else
+    return epilogue == EPI_LOGPSD && (nfft == (1 << 20) || nfft == (1 << 21) || nfft == (1 << 22));
+#endif
+}
+
 bool fft_tiled2_split(int nfft, int* log2a, int* log2m) {
     int lg = 0;
     while ((1 << lg) < nfft) ++lg;
@@ -629,7 +690,7 @@ template <int LOG2A, int W>
 static hipError_t launch_col_staged(const LaunchArgs& a, const float2* src, size_t nf, int M) {
     using C = LdsCfg<LOG2A>;
     const unsigned tiles = (unsigned)(M / W);
-    unsigned grid = (unsigned)a.num_cus;
+    unsigned grid = (unsigned)a.num_cus * staged_per_cu(C::SLOT, C::N, W);
     if (grid >= tiles) grid -= grid % tiles;             // whole runs of frames per tile position
     const size_t lds_bytes = ((size_t)C::SLOT * W + (size_t)C::N * W) * sizeof(float2);
     const float2* twA = static_cast<const float2*>(a.d_twiddle_2p);
@@ -657,10 +718,10 @@ static hipError_t launch_col_tiles(const LaunchArgs& a, const float2* src, size_
     const size_t lds_bytes = (size_t)(C::SLOT) * W * sizeof(float2);
     const unsigned tiles = (unsigned)(M / W);
     const size_t items = nf * (size_t)tiles;
-    if (W == 8) grid_cap = (unsigned)a.num_cus * 2;
     // The software-pipelined (FIXED) instances hold two tiles and their per-position factors in registers
     // (<= 168 VGPRs): 3 workgroups per CU are resident, and a persistent grid must not exceed what is resident.
-    constexpr bool CAN_FIX = C::T * W <= 256 && W >= 16;
+    constexpr bool CAN_FIX = col_can_fix(C::T, W);
+    if (W == 8 && !CAN_FIX) grid_cap = (unsigned)a.num_cus * 2;
     if (CAN_FIX && grid_cap > (unsigned)a.num_cus * 3) grid_cap = (unsigned)a.num_cus * 3;
     unsigned grid = (unsigned)(items < grid_cap ? items : grid_cap);
     if (W == 8 && grid >= 16) grid &= ~15u;
@@ -709,7 +770,7 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
 
 // row pass through row_pass_pair_kernel (M >= 1024): as many workgroups per CU as their LDS allows
 template <int LOG2M>
-static hipError_t launch_row_pair(const LaunchArgs& a, void* dst, size_t nf, int A) {
+static hipError_t launch_row_pair(const LaunchArgs& a, void* dst, size_t nf, int A, float* mip) {
     using C = LdsCfg<LOG2M>;
     const size_t items = nf * (size_t)(A / 16);
     const size_t xch = (size_t)8 * C::SLOT * sizeof(float2), ctile = (size_t)C::N * 9 * sizeof(float2);
@@ -727,12 +788,17 @@ static hipError_t launch_row_pair(const LaunchArgs& a, void* dst, size_t nf, int
             const size_t lds_h = (size_t)HR * C::SLOT * sizeof(float2);
             const size_t caph = (size_t)a.num_cus * (8 / HR);
             const unsigned gh = (unsigned)(items < caph ? items : caph);
-            auto kernh = row_pass_wave_kernel<LOG2M, HR>;
-            static std::atomic<uint64_t> lds_ok_h{0};
-            hipError_t eh = ensure_dynamic_lds(reinterpret_cast<const void*>(kernh), lds_h, lds_ok_h);
-            if (eh != hipSuccess) return eh;
-            hipLaunchKernelGGL(kernh, dim3(gh), dim3(64 * HR), lds_h, a.stream, static_cast<const float2*>(a.d_scratch),
-                               static_cast<float*>(dst), nf, A, twM, a.eps, a.shift);
+#define SDRK_ROWW(MIPV)                                                                                          \
+    do {                                                                                                         \
+        auto kernh = row_pass_wave_kernel<LOG2M, HR, MIPV>;                                                      \
+        static std::atomic<uint64_t> lds_ok_h{0};                                                                \
+        hipError_t eh = ensure_dynamic_lds(reinterpret_cast<const void*>(kernh), lds_h, lds_ok_h);               \
+        if (eh != hipSuccess) return eh;                                                                         \
+        hipLaunchKernelGGL(kernh, dim3(gh), dim3(64 * HR), lds_h, a.stream, static_cast<const float2*>(a.d_scratch), \
+                           static_cast<float*>(dst), nf, A, twM, a.eps, a.shift, mip);                           \
+    } while (0)
+            if (mip) SDRK_ROWW(true); else SDRK_ROWW(false);
+#undef SDRK_ROWW
             return hipGetLastError();
         }
     }
@@ -752,10 +818,10 @@ static hipError_t launch_row_pair(const LaunchArgs& a, void* dst, size_t nf, int
 }
 
 template <int LOG2M>
-static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, unsigned grid_cap) {
+static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, unsigned grid_cap, float* mip) {
     using C = LdsCfg<LOG2M>;
     if constexpr (LOG2M >= 10) {
-        return launch_row_pair<LOG2M>(a, dst, nf, A);
+        return launch_row_pair<LOG2M>(a, dst, nf, A, mip);
     } else {
         constexpr int ROWS = 16;
         // LDS: the exchange area (ROWS x 17/16 M complex) or the complex transpose tile (M x (ROWS+1)), whichever is larger
@@ -804,9 +870,9 @@ static hipError_t launch_fft_tiled2_serial(const LaunchArgs& a) {
     {
         auto gcd = [](size_t x, size_t y) { while (y) { size_t t = x % y; x = y; y = t; } return x; };
         const int Wc = COL_TILE_W(la <= 11 ? la : 11), Rr = 16;
-        const bool pipelined = (A / 16) * Wc <= 256 && Wc >= 16;
-        size_t col_grid = STAGED_W(la) ? (size_t)a.num_cus
-                        : (Wc == 8 ? (size_t)a.num_cus * 2 : (pipelined ? (size_t)a.num_cus * 3 : cap(A < 1024 ? A : 1024)));
+        const bool pipelined = col_can_fix(A / 16, Wc);
+        size_t col_grid = STAGED_W(la) ? (size_t)a.num_cus * staged_per_cu(A + A / 16, A, Wc)
+                        : (pipelined ? (size_t)a.num_cus * 3 : (Wc == 8 ? (size_t)a.num_cus * 2 : cap(A < 1024 ? A : 1024)));
         if (pipelined && col_grid > cap(A)) col_grid = cap(A);
         const size_t row_grid = M >= 2048 ? (size_t)a.num_cus : (M == 1024 ? (size_t)a.num_cus * 2 : cap(M));
         size_t cw = col_grid / (size_t)(M / Wc), rw = row_grid / (size_t)(A / Rr);
@@ -828,11 +894,12 @@ static hipError_t launch_fft_tiled2_serial(const LaunchArgs& a) {
             default: e = launch_col<11>(a, src, nf, M, cap(1024)); break;
         }
         if (e != hipSuccess) return e;
+        float* mip = (a.d_mip && fft_tiled2_has_mip(a.nfft, a.epilogue)) ? a.d_mip + f0 * (size_t)(a.nfft / 16) : nullptr;
         switch (lm) {
-            case 8: e = launch_row<8>(a, dst, nf, A, cap(M)); break;
-            case 9: e = launch_row<9>(a, dst, nf, A, cap(M)); break;
-            case 10: e = launch_row<10>(a, dst, nf, A, cap(M)); break;
-            default: e = launch_row<11>(a, dst, nf, A, cap(1024)); break;
+            case 8: e = launch_row<8>(a, dst, nf, A, cap(M), nullptr); break;
+            case 9: e = launch_row<9>(a, dst, nf, A, cap(M), nullptr); break;
+            case 10: e = launch_row<10>(a, dst, nf, A, cap(M), nullptr); break;
+            default: e = launch_row<11>(a, dst, nf, A, cap(1024), mip); break;
         }
         if (e != hipSuccess) return e;
     }
@@ -849,12 +916,12 @@ static hipError_t col_pass(const LaunchArgs& a, int la, const float2* src, size_
         default: return launch_col<11>(a, src, nf, M, grid_cap_1024);
     }
 }
-static hipError_t row_pass(const LaunchArgs& a, int lm, void* dst, size_t nf, int A, unsigned grid_cap, unsigned grid_cap_1024) {
+static hipError_t row_pass(const LaunchArgs& a, int lm, void* dst, size_t nf, int A, unsigned grid_cap, unsigned grid_cap_1024, float* mip) {
     switch (lm) {
-        case 8: return launch_row<8>(a, dst, nf, A, grid_cap);
-        case 9: return launch_row<9>(a, dst, nf, A, grid_cap);
-        case 10: return launch_row<10>(a, dst, nf, A, grid_cap);
-        default: return launch_row<11>(a, dst, nf, A, grid_cap_1024);
+        case 8: return launch_row<8>(a, dst, nf, A, grid_cap, nullptr);
+        case 9: return launch_row<9>(a, dst, nf, A, grid_cap, nullptr);
+        case 10: return launch_row<10>(a, dst, nf, A, grid_cap, nullptr);
+        default: return launch_row<11>(a, dst, nf, A, grid_cap_1024, mip);
     }
 }
 
@@ -885,9 +952,9 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
     auto round_chunk = [&](size_t chunk) {
         auto gcd = [](size_t x, size_t y) { while (y) { size_t t = x % y; x = y; y = t; } return x; };
         const int Wc = COL_TILE_W(la <= 11 ? la : 11), Rr = 16;
-        const bool pipelined = (A / 16) * Wc <= 256 && Wc >= 16;
-        size_t col_grid = STAGED_W(la) ? (size_t)ccus
-                        : (Wc == 8 ? (size_t)ccus * 2 : (pipelined ? (size_t)ccus * 3 : cap(A < 1024 ? A : 1024, ccus)));
+        const bool pipelined = col_can_fix(A / 16, Wc);
+        size_t col_grid = STAGED_W(la) ? (size_t)ccus * staged_per_cu(A + A / 16, A, Wc)
+                        : (pipelined ? (size_t)ccus * 3 : (Wc == 8 ? (size_t)ccus * 2 : cap(A < 1024 ? A : 1024, ccus)));
         if (pipelined && col_grid > cap(A, ccus)) col_grid = cap(A, ccus);
         const size_t row_grid = M >= 2048 ? (size_t)rcus : (M == 1024 ? (size_t)rcus * 2 : cap(M, rcus));
         size_t cw = col_grid / (size_t)(M / Wc), rw = row_grid / (size_t)(A / Rr);
@@ -919,7 +986,8 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
             if (e == hipSuccess) e = hipEventRecord(a.ev_col[h], a.stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(a.stream2, a.ev_col[h], 0);
             if (e != hipSuccess) return e;
-            e = row_pass(ra, lm, static_cast<char*>(a.d_out) + f0 * (size_t)a.nfft * out_elem, nf, A, cap(M, rcus), cap(1024, rcus));
+            float* mip = (a.d_mip && fft_tiled2_has_mip(a.nfft, a.epilogue)) ? a.d_mip + f0 * (size_t)(a.nfft / 16) : nullptr;
+            e = row_pass(ra, lm, static_cast<char*>(a.d_out) + f0 * (size_t)a.nfft * out_elem, nf, A, cap(M, rcus), cap(1024, rcus), mip);
             if (e == hipSuccess) e = hipEventRecord(a.ev_row[h], a.stream2);
             if (e != hipSuccess) return e;
         }

@@ -36,6 +36,9 @@ struct LaunchArgs {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_col[2] = {nullptr, nullptr}, ev_row[2] = {nullptr, nullptr}, ev_fork = nullptr;
     int col_cus = 0, row_cus = 0;
+    // optional second output of the frame lengths for which fft_tiled2_has_mip() holds: every row max-hold-decimated by 16,
+    // float32[n_frames][nfft / 16] as [band = k3 / 16][km] (fft_tiled2.hip, row_pass_wave_kernel<…, MIP>); ignored elsewhere
+    float* d_mip = nullptr;
 };
 
 // 20*log10(sqrt(re^2+im^2) + eps), the expression order of streamer.py:121:
@@ -78,6 +81,7 @@ bool fft_lds_supports(int nfft);                     // 16 .. 16384 except 4096:
 hipError_t launch_fft_lds(const LaunchArgs& a);
 bool fft_tiled2_split(int nfft, int* log2a, int* log2m);   // 2^15 .. 2^22: N = A * M, both in LDS
 hipError_t launch_fft_tiled2(const LaunchArgs& a);
+bool fft_tiled2_has_mip(int nfft, int epilogue);           // does the transform honour LaunchArgs::d_mip at this length?
 hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frames, int nfft,
                              void* d_iq, hipStream_t stream);
 
@@ -112,6 +116,9 @@ hipError_t launch_row_peaks(const float* d_rows, size_t n_rows, int nfft, const 
                             int max_peaks, int* d_idx, int* d_count, hipStream_t s);
 hipError_t launch_decimate_rows(const float* d_ring, int nfft, int maxlen, int start_slot, int n_rows, int factor,
                                 int mode, float* d_out, hipStream_t stream);
+// the same max-hold read-out from the by-16 rows the transform left beside the ring (factor a multiple of 16)
+hipError_t launch_decimate_mip(const float* d_mip_ring, int nfft, int maxlen, int start_slot, int n_rows, int factor,
+                               float* d_out, hipStream_t stream);
 hipError_t launch_stream_mix(const void* d_in, void* d_out, size_t n_frames4096, int num_cus, hipStream_t stream);
 hipError_t launch_copy_1to1(const void* d_in, void* d_out, size_t bytes, int num_cus, int blocks_per_cu, hipStream_t stream);
 hipError_t launch_power_mean(const void* d_spec, size_t n_frames, int nfft, float scale, float* d_out,

@@ -149,9 +149,14 @@ def plan_pinning(n_devices: int, in_bytes: int, pageable_fraction: float, sighti
                        f"staging costs {gain:.1f} ms more than pinned arrays per call, page-locking {register:.0f} ms once")
 
 
+# key of a call's arrays -> (count, weak references to the arrays that OWN the memory).  An entry counts only while those
+# very owners are alive: a fresh array that the allocator happens to put at a recycled address starts from zero.
 _sightings: dict = {}
-_auto_registered: dict = {}
-_auto_lock = threading.Lock()
+_auto_registered: dict = {}          # base address -> bytes, page-locked by _register_for_life
+_not_registrable: set = set()        # base addresses hipHostRegister has refused (overlap with a user registration ...)
+# Re-entrant: a finaliser (undo below) that the cyclic collector runs while this thread is inside a locked region must
+# not deadlock; the finaliser itself does not take the lock at all (dict.pop is atomic under the GIL).
+_auto_lock = threading.RLock()
 _warned = False
 
 
@@ -163,9 +168,29 @@ def _owner(a: np.ndarray):
     return o
 
 
+def _count_sighting(arrays) -> int:
+    """How many auto-mode calls, this one included, have handed in THESE arrays (same address, same size, same owning
+    objects still alive).  Arrays whose owner cannot be weakly referenced never accumulate."""
+    key = tuple((a.ctypes.data, a.nbytes) for a in arrays)
+    owners = [_owner(a) for a in arrays]
+    try:
+        refs = tuple(weakref.ref(o) for o in owners)
+    except TypeError:
+        return 1
+    with _auto_lock:
+        if len(_sightings) > 64:
+            _sightings.clear()
+        count, old = _sightings.get(key, (0, ()))
+        if len(old) != len(owners) or any(r() is not o for r, o in zip(old, owners)):
+            count = 0                                   # another array at a recycled address, or the first sighting
+        _sightings[key] = (count + 1, refs)
+        return count + 1
+
+
 def _register_for_life(a: np.ndarray) -> bool:
     """Page-lock the whole allocation ``a`` lives in and undo it when the owning array is collected.  False (nothing
-    done) when the owner is not a numpy array that owns its data, or cannot carry a finaliser."""
+    done, the caller stages) when the owner is not a numpy array that owns its data, cannot carry a finaliser, or the
+    registration is refused (e.g. the range overlaps one the user registered)."""
     root = _owner(a)
     if not isinstance(root, np.ndarray) or not root.flags.owndata or not root.flags.c_contiguous or root.nbytes == 0:
         return False
@@ -175,42 +200,55 @@ def _register_for_life(a: np.ndarray) -> bool:
     with _auto_lock:
         if ptr in _auto_registered:
             return True
-        check(lib().sdrk_host_register(c_void_p(ptr), c_size_t(nbytes)))
+        if ptr in _not_registrable:
+            return False
+        try:
+            check(lib().sdrk_host_register(c_void_p(ptr), c_size_t(nbytes)))
+        except (ValueError, MemoryError, _ffi.SdrkError):
+            if len(_not_registrable) > 256:
+                _not_registrable.clear()
+            _not_registrable.add(ptr)
+            return False
         _auto_registered[ptr] = nbytes
 
-        def undo(p=ptr):
-            with _auto_lock:
-                _auto_registered.pop(p, None)
-            try:
-                lib().sdrk_host_unregister(c_void_p(p))
-            except Exception:               # noqa: BLE001 - interpreter shutdown
-                pass
+    def undo(p=ptr):
+        _auto_registered.pop(p, None)        # no lock: may run from the collector inside a locked region of any thread
+        _not_registrable.discard(p)
+        try:
+            lib().sdrk_host_unregister(c_void_p(p))
+        except Exception:                   # noqa: BLE001 - interpreter shutdown
+            pass
 
-        weakref.finalize(root, undo)         # runs before numpy frees the memory (weak references are cleared first)
+    weakref.finalize(root, undo)             # runs before numpy frees the memory (weak references are cleared first)
     return True
 
 
 COSTS = HostCosts()          # what pin="auto" reckons with (a deployment on other hardware may replace it)
 
 
-def auto_pin(arrays, n_devices: int, in_bytes: int, costs: Optional[HostCosts] = None, cores: Optional[int] = None) -> PinDecision:
+def auto_pin(arrays, n_devices: int, in_bytes: int, costs: Optional[HostCosts] = None, cores: Optional[int] = None,
+             temporaries=()) -> PinDecision:
     """Apply ``plan_pinning`` to the host arrays of one call (frames and rows): count the sighting, register what the
-    decision says, warn once where the host bounds a multi-GPU call.  Returns the decision (tests read it)."""
+    decision says, warn once where the host bounds a multi-GPU call.  Returns the decision (tests read it).
+
+    ``temporaries``: arrays of the call that the library made itself (a result for ``out=None``, a complex64 copy of
+    other input).  They weigh in the call's pageable share but are never counted as seen again and never page-locked:
+    a fresh array per call would pay ``hipHostRegister`` (and the page faults it forces) every time, for nothing."""
     global _warned
     arrays = [a for a in arrays if a is not None and a.nbytes]
-    total = sum(a.nbytes for a in arrays)
+    temporaries = [a for a in temporaries if a is not None and a.nbytes]
+    total = sum(a.nbytes for a in arrays) + sum(a.nbytes for a in temporaries)
     pageable = [a for a in arrays if not is_pinned(a)]
-    frac = (sum(a.nbytes for a in pageable) / total) if total else 0.0
-    key = tuple((a.ctypes.data, a.nbytes) for a in arrays)
-    with _auto_lock:
-        if len(_sightings) > 64:
-            _sightings.clear()
-        n = _sightings[key] = _sightings.get(key, 0) + 1
+    frac = ((sum(a.nbytes for a in pageable) + sum(a.nbytes for a in temporaries)) / total) if total else 0.0
+    n = _count_sighting(arrays) if arrays and not temporaries else 1
     d = plan_pinning(n_devices, in_bytes, frac, n, usable_cpus() if cores is None else cores, COSTS if costs is None else costs)
+    if d.mode == "register" and temporaries:
+        d = dataclasses.replace(d, mode="stage", reason=d.reason + "; but the call owns a temporary array (fresh every call): staged")
     if d.mode == "register":
         done = [_register_for_life(a) for a in pageable]
         if not all(done):
-            d = dataclasses.replace(d, mode="stage", reason=d.reason + "; but an array's memory is not owned by a numpy array: staged")
+            d = dataclasses.replace(d, mode="stage", reason=d.reason + "; but an array's memory cannot be page-locked "
+                                    "(not owned by a numpy array, or the registration was refused): staged")
     elif d.warn and not _warned:
         _warned = True
         warnings.warn(

@@ -61,7 +61,12 @@ def spectrum_db_sharded(samples, devices: Sequence[int], *, window=None, eps: fl
     x = _as_c64(samples)
     if x.ndim != 2:
         raise ValueError("sharding needs a (B, N) batch")
-    out = SpectrumPlan._out_array(out, x.shape, np.float32)
+    own = [] if x is samples or (isinstance(samples, np.ndarray) and np.may_share_memory(x, samples)) else [x]
+    if out is None:
+        out = SpectrumPlan._out_array(None, x.shape, np.float32)
+        own.append(out)                      # arrays this call made itself: never counted, never page-locked
+    else:
+        out = SpectrumPlan._out_array(out, x.shape, np.float32)
     if pin not in ("auto", True, False):
         raise ValueError("pin must be 'auto', True or False")
     if pin is True and x.nbytes:
@@ -72,7 +77,7 @@ def spectrum_db_sharded(samples, devices: Sequence[int], *, window=None, eps: fl
                     stack.enter_context(hostmem.registered(a))
             return spectrum_db_sharded(x, devices, window=window, eps=eps, shift=shift, out=out, pin=False)
     if pin == "auto" and x.nbytes:
-        hostmem.auto_pin([x, out], len(devices), x.nbytes)
+        hostmem.auto_pin([a for a in (x, out) if not any(a is t for t in own)], len(devices), x.nbytes, temporaries=own)
     ranges = shard_ranges(x.shape[0], len(devices))
     errors: List[BaseException] = []
 

@@ -82,6 +82,7 @@ class SpectrumPlan:
         self.shift = bool(shift)
         self.device = int(device)
         self._lock = threading.Lock()
+        self.last_placement: Optional[dict] = None     # report of the last tune_scratch() on this plan
         self._handle = c_void_p()
         wptr = warr.ctypes.data_as(c_void_p) if warr is not None else None
         # fused64k: the experimental single-launch form of N = 65536; an explicit plan
@@ -224,6 +225,7 @@ class SpectrumPlan:
         with self._lock:
             check(lib().sdrk_plan_tune_scratch(self.handle, c_void_p(d_iq), c_size_t(n_frames), c_size_t(stride),
                                                c_void_p(d_out), int(candidates), ms, byref(chosen)))
+            self.last_placement = placement_report()
         return [float(v) for v in ms], int(chosen.value)
 
     def exec_device_timed_each(self, d_iq: int, n_frames: int, d_out: int, launches: int = 1, *,
@@ -257,6 +259,20 @@ class SpectrumPlan:
         ms, n = (c_float * 16)(), c_int(0)
         check(lib().sdrk_plan_staging_probe(self.handle, ms, 16, byref(n)))
         return [float(ms[i]) for i in range(min(int(n.value), 16))]
+
+
+def placement_report() -> dict:
+    """What the last placement probe on this thread did (``sdrk_placement_report``): the warm-up, candidate 0 as first timed
+    and as timed again after the last candidate, the kept candidate's time (ms); ``gain_vs_retimed_first`` is what the kept
+    candidate saves against candidate 0 measured WARM — the honest figure (a first timing taken before the shader clock had
+    ramped up would credit the ramp to the placement)."""
+    warm, n, first, again, kept = c_float(0), c_int(0), c_float(0), c_float(0), c_float(0)
+    tried = int(lib().sdrk_placement_report(byref(warm), byref(n), byref(first), byref(again), byref(kept)))
+    rec = {"candidates_tried": tried, "warmup_ms": round(float(warm.value), 2), "warmup_launches": int(n.value),
+           "first_ms": round(float(first.value), 4), "retimed_first_ms": round(float(again.value), 4),
+           "chosen_ms": round(float(kept.value), 4)}
+    rec["gain_vs_retimed_first"] = (round(1.0 - kept.value / again.value, 4) if again.value > 0 and kept.value > 0 else None)
+    return rec
 
 
 # ---- plan cache for the function API -------------------------------------------

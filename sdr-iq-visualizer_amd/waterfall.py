@@ -39,19 +39,24 @@ class WaterfallBuffer:
         self.nfft, self.maxlen, self.device = nfft, maxlen, int(device)
         self._window, self._eps = window, float(eps)
         self._plan: Optional[SpectrumPlan] = None
+        self._gather: Optional[np.ndarray] = None     # the array a gather_begin() is filling (kept alive until gather_end())
         self._lock = threading.Lock()
         self._handle = c_void_p()
         check(lib().sdrk_waterfall_create(self.device, nfft, maxlen, byref(self._handle)))
 
     # -- lifetime ---------------------------------------------------------------
     def close(self) -> None:
-        h, self._handle = self._handle, c_void_p()
-        if h:
-            lib().sdrk_waterfall_destroy(h)       # (waits for a copy that gather_begin may have left in flight)
-        self._gather = None
-        if self._plan is not None:
-            self._plan.close()
-            self._plan = None
+        # under the lock every other method holds across its C call: an append / read in flight on another thread (the
+        # reference appends from Flask request threads, callbacks.py:96,176) finishes on the live ring, and whoever comes
+        # after finds the handle gone ("waterfall is closed") instead of a destroyed one
+        with self._lock:
+            h, self._handle = self._handle, c_void_p()
+            if h:
+                lib().sdrk_waterfall_destroy(h)   # (waits for a copy that gather_begin may have left in flight)
+            self._gather = None
+            if self._plan is not None:
+                self._plan.close()
+                self._plan = None
 
     def __enter__(self) -> "WaterfallBuffer":
         return self
@@ -72,7 +77,18 @@ class WaterfallBuffer:
 
     # -- deque-like interface ------------------------------------------------------
     def __len__(self) -> int:
+        with self._lock:
+            return self._rows()
+
+    def _rows(self) -> int:                       # caller holds the lock
         return check(lib().sdrk_waterfall_rows(self._h()))
+
+    def maxhold16_rows(self) -> int:
+        """How many of the valid rows carry the by-16 max-hold companion the N >= 2^20 transform writes beside the ring
+        (``sdrk_waterfall_maxhold16_rows``): a max-mode ``decimate=`` read-out with a factor that is a multiple of 16 over
+        such rows reads 1/16 of the bytes."""
+        with self._lock:
+            return check(lib().sdrk_waterfall_maxhold16_rows(self._h()))
 
     def clear(self) -> None:
         with self._lock:
@@ -151,7 +167,7 @@ class WaterfallBuffer:
         if decimate < 1 or self.nfft % decimate:
             raise ValueError(f"decimate={decimate} must divide nfft={self.nfft}")
         with self._lock:
-            rows = len(self) if max_rows is None else min(len(self), int(max_rows))
+            rows = self._rows() if max_rows is None else min(self._rows(), int(max_rows))
             bins = self.nfft // decimate
             if out is None:
                 out = np.empty((rows, bins), dtype=np.float32)
@@ -167,7 +183,7 @@ class WaterfallBuffer:
         """Second half: wait for the copy started by ``gather_begin`` and return its array."""
         with self._lock:
             check(lib().sdrk_waterfall_read_decimated_end(self._h()))
-            g, self._gather = getattr(self, "_gather", None), None
+            g, self._gather = self._gather, None
             return g
 
     def as_array(self, max_rows: Optional[int] = None, *, decimate: int = 1, mode: str = "max") -> np.ndarray:
@@ -181,14 +197,14 @@ class WaterfallBuffer:
             if decimate < 1 or self.nfft % decimate:
                 raise ValueError(f"decimate={decimate} must divide nfft={self.nfft}")
             with self._lock:
-                rows = len(self) if max_rows is None else min(len(self), int(max_rows))
+                rows = self._rows() if max_rows is None else min(self._rows(), int(max_rows))
                 out = np.empty((rows, self.nfft // decimate), dtype=np.float32)
                 got = c_size_t(0)
                 check(lib().sdrk_waterfall_read_decimated(self._h(), out.ctypes.data_as(c_void_p), c_size_t(rows),
                                                           int(decimate), 0 if mode == "max" else 1, byref(got)))
                 return out[: got.value]
         with self._lock:
-            rows = len(self)
+            rows = self._rows()
             if max_rows is not None:
                 rows = min(rows, int(max_rows))
             out = np.empty((rows, self.nfft), dtype=np.float32)

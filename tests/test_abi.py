@@ -43,7 +43,7 @@ def test_version_and_error_string_without_gpu():
     from sdr_iq_visualizer_amd import _ffi
     lib = _ffi.lib()
     header = int(re.search(r"#define\s+SDRK_VERSION\s+(\d+)", open(HEADER).read()).group(1))
-    assert lib.sdrk_version() == header == _ffi.ABI_VERSION == 400
+    assert lib.sdrk_version() == header == _ffi.ABI_VERSION == 500
     assert isinstance(lib.sdrk_last_error(), bytes)
     assert lib.sdrk_device_count() >= 0
 
@@ -52,11 +52,11 @@ def test_stale_library_is_refused_with_a_clear_message(monkeypatch):
     """A libsdrk.so built from an older header must not surface as an AttributeError on some newer symbol."""
     from sdr_iq_visualizer_amd import _ffi
     monkeypatch.setattr(_ffi, "_lib", None)
-    monkeypatch.setattr(_ffi, "ABI_VERSION", 401)
-    with pytest.raises(ImportError, match="reports ABI version 400, this package expects 401"):
+    monkeypatch.setattr(_ffi, "ABI_VERSION", 501)
+    with pytest.raises(ImportError, match="reports ABI version 500, this package expects 501"):
         _ffi.lib()
-    monkeypatch.setattr(_ffi, "ABI_VERSION", 400)
-    assert _ffi.lib().sdrk_version() == 400
+    monkeypatch.setattr(_ffi, "ABI_VERSION", 500)
+    assert _ffi.lib().sdrk_version() == 500
 
 
 def test_product_path_fails_loudly_without_a_device():
@@ -102,7 +102,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     exe = _build_c_smoke(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    assert "sdrk 400" in out.stdout
+    assert "sdrk 500" in out.stdout
 
 
 @pytest.mark.gpu

@@ -1,0 +1,225 @@
+"""Sanitizer and re-entrancy legs for the host side (CPU; SURVEY.md §5 "race detection / sanitizers").
+
+The reference shares state between its reader thread and Flask request threads without any synchronisation
+(app/sdr/streamer.py:19-21,100-101; app/dashboard/callbacks.py:19,96; app/processing/classifier.py:5-6).  This package
+answers with locks, a process-wide copy-thread pool and finalisers; these tests put them under the tools that find
+what such code gets wrong: ThreadSanitizer and AddressSanitizer + UBSan on the pool (csrc/host_pool.h, built from
+tests/host_pool_stress.cpp with g++), and a forced garbage collection inside the locked regions of hostmem."""
+import gc
+import os
+import shutil
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def stress_binaries(tmp_path_factory):
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    out = tmp_path_factory.mktemp("san")
+    src = os.path.join(HERE, "host_pool_stress.cpp")
+    built = {}
+    for name, flags in (("tsan", ["-fsanitize=thread"]),
+                        ("asan_ubsan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])):
+        exe = str(out / f"host_pool_{name}")
+        r = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-pthread", *flags, src, "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        built[name] = exe
+    return built
+
+
+@pytest.mark.parametrize("helpers", [0, 1, 7])
+@pytest.mark.parametrize("san", ["tsan", "asan_ubsan"])
+def test_copy_pool_under_sanitizers(stress_binaries, san, helpers):
+    """Six caller threads, sizes around the pool's 2 x PIECE threshold, pools of 0 / 1 / 7 helpers: every copy exact,
+    no report from the sanitizer (a report makes the process exit non-zero: halt_on_error / exitcode)."""
+    env = dict(os.environ, SDRK_HOST_THREADS=str(helpers),
+               TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67",
+               UBSAN_OPTIONS="halt_on_error=1 print_stacktrace=1")
+    r = subprocess.run([stress_binaries[san], "6", "10"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert f"helpers={helpers} " in r.stdout and "bad=0" in r.stdout
+
+
+class _FakeLib:
+    """hipHostRegister / Unregister stand-ins that record their calls; `on_register` runs INSIDE hostmem's locked region."""
+
+    def __init__(self, on_register=None, refuse=()):
+        self.registered, self.unregistered, self.on_register, self.refuse = [], [], on_register, set(refuse)
+
+    def sdrk_host_register(self, ptr, nbytes):
+        if ptr.value in self.refuse:
+            return -3
+        if self.on_register:
+            self.on_register()
+        self.registered.append(ptr.value)
+        return 0
+
+    def sdrk_host_unregister(self, ptr):
+        self.unregistered.append(ptr.value)
+        return 0
+
+    def sdrk_host_is_pinned(self, ptr, nbytes):
+        return 1 if ptr.value in self.registered and ptr.value not in self.unregistered else 0
+
+    def sdrk_last_error(self):
+        return b"refused by the test"
+
+
+class _Cycle:
+    """Keeps an array alive through a reference cycle: only the cyclic collector frees it."""
+
+    def __init__(self, arr):
+        self.arr, self.me = arr, self
+
+
+def _patched(monkeypatch, fake):
+    from sdr_iq_visualizer_amd import hostmem as h
+    from sdr_iq_visualizer_amd import _ffi
+    monkeypatch.setattr(h, "lib", lambda: fake)
+    monkeypatch.setattr(_ffi, "lib", lambda: fake)          # check() reads the error text through _ffi.lib()
+    monkeypatch.setattr(h, "_sightings", {})
+    monkeypatch.setattr(h, "_auto_registered", {})
+    monkeypatch.setattr(h, "_not_registrable", set())
+    return h
+
+
+def test_finaliser_inside_the_locked_region_does_not_deadlock(monkeypatch):
+    """A garbage collection that happens while a thread is inside hostmem's locked region (registering array B) and that
+    collects an auto-registered array A held in a cycle runs A's finaliser on that same thread.  With a plain Lock
+    taken by the finaliser that is a deadlock (round 4's hostmem.py:181); it must simply unregister A."""
+    fake = _FakeLib()
+    h = _patched(monkeypatch, fake)
+    a = np.zeros(1 << 16, dtype=np.float32)
+    pa = a.ctypes.data
+    assert h._register_for_life(a) and pa in h._auto_registered
+    holder = _Cycle(a)
+    del a, holder                                            # alive only through the cycle now
+    fake.on_register = gc.collect                            # the collection runs inside the `with _auto_lock` of B's call
+    b = np.zeros(1 << 16, dtype=np.float32)
+    done = []
+    t = threading.Thread(target=lambda: done.append(h._register_for_life(b)), daemon=True)
+    t.start()
+    t.join(20)
+    assert not t.is_alive(), "deadlock: the finaliser waited for the lock its own thread holds"
+    assert done == [True]
+    assert pa in fake.unregistered and pa not in h._auto_registered and b.ctypes.data in h._auto_registered
+    # ... and the same through auto_pin's own locked region (the sighting count), many times, from several threads
+    fake.on_register = None
+    errors = []
+
+    def churn(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for _ in range(60):
+                x = np.zeros(int(rng.integers(1, 4)) << 14, dtype=np.complex64)
+                keep = _Cycle(x)
+                for _k in range(3):
+                    d = h.auto_pin([x], 8, 8 << 30, cores=1)       # one core: registers at the first sighting
+                    assert d.mode in ("register", "as-is"), d
+                del x, keep
+                if rng.integers(0, 3) == 0:
+                    gc.collect()
+        except BaseException as e:                             # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=churn, args=(s,), daemon=True) for s in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not any(t.is_alive() for t in ts) and not errors, errors
+    gc.collect()
+    assert set(fake.registered) - set(fake.unregistered) == {b.ctypes.data}    # everything that died was unregistered
+
+
+def test_a_recycled_address_does_not_inherit_sightings(monkeypatch):
+    """sightings were keyed by (address, nbytes) alone, so a fresh result array that the allocator put
+    at a recycled address inherited the count of its predecessors and was page-locked (and unlocked) on every call."""
+    fake = _FakeLib()
+    h = _patched(monkeypatch, fake)
+    claimed, seen_addresses, modes = 8 << 30, set(), []
+    for _ in range(40):                                       # a new array per "call", as `rows = spectrum_db(x, ...)` makes
+        out = np.empty((64, 4096), dtype=np.float32)
+        seen_addresses.add(out.ctypes.data)
+        modes.append(h.auto_pin([out], 8, claimed, cores=16).mode)
+        del out
+    assert len(seen_addresses) < 40, "the allocator never recycled an address: the test would prove nothing"
+    assert set(modes) == {"stage"} and not fake.registered
+    # the SAME array handed in again and again still accumulates (4 x staged, then registered: the ski-rental point)
+    keep = np.empty((64, 4096), dtype=np.float32)
+    assert [h.auto_pin([keep], 8, claimed, cores=16).mode for _ in range(6)] == ["stage"] * 4 + ["register", "as-is"]
+    # arrays the library made itself for this call are never counted and never page-locked, whatever the count says
+    tmp = np.empty((64, 4096), dtype=np.float32)
+    for _ in range(8):
+        d = h.auto_pin([keep], 8, claimed, cores=1, temporaries=[tmp])
+        assert d.mode == "stage"
+    assert fake.registered == [keep.ctypes.data]
+
+
+def test_a_refused_registration_falls_back_to_staging(monkeypatch):
+    """hipHostRegister can refuse (the range overlaps a registration the user made): the call that decides to register
+    must stage instead of raising, and must not try again on every later call."""
+    x = np.zeros((64, 4096), dtype=np.complex64)
+    fake = _FakeLib(refuse=[x.ctypes.data])
+    h = _patched(monkeypatch, fake)
+    for _ in range(3):
+        d = h.auto_pin([x], 8, 8 << 30, cores=1)
+        assert d.mode == "stage" and "cannot be page-locked" in d.reason
+    assert not fake.registered and x.ctypes.data in h._not_registrable
+
+
+def test_waterfall_close_is_serialised_with_calls_in_flight(monkeypatch):
+    """WaterfallBuffer.close() used to swap and destroy the handle without the lock: an append in flight on another
+    thread (the reference appends from Flask request threads) could use a destroyed ring.  With the library stubbed:
+    a close issued while an append sits inside its C call returns only after that call, and later calls raise."""
+    from sdr_iq_visualizer_amd import waterfall as w
+    import time
+    events, gate = [], threading.Event()
+
+    class Lib:
+        def sdrk_waterfall_create(self, dev, nfft, maxlen, out):
+            out._obj.value = 1234
+            return 0
+
+        def sdrk_waterfall_append_rows(self, h, rows, n):
+            events.append("append begins")
+            gate.wait(5)
+            time.sleep(0.05)
+            events.append("append ends")
+            return 0
+
+        def sdrk_waterfall_destroy(self, h):
+            events.append("destroy")
+            return 0
+
+        def sdrk_waterfall_rows(self, h):
+            return 0
+
+    fake = Lib()
+    monkeypatch.setattr(w, "lib", lambda: fake)
+    monkeypatch.setattr(w._ffi, "require_device", lambda d: None)
+    wf = w.WaterfallBuffer(8, maxlen=4)
+    assert wf._gather is None                                   # initialised in __init__, not on first use
+    t = threading.Thread(target=lambda: wf.append_rows(np.zeros(8, np.float32)))
+    t.start()
+    while "append begins" not in events:
+        time.sleep(0.001)
+    closer = threading.Thread(target=wf.close)
+    closer.start()
+    time.sleep(0.02)
+    assert events == ["append begins"]                           # close is waiting for the lock
+    gate.set()
+    t.join(5)
+    closer.join(5)
+    assert events == ["append begins", "append ends", "destroy"]
+    with pytest.raises(RuntimeError, match="closed"):
+        wf.append_rows(np.zeros(8, np.float32))
+    with pytest.raises(RuntimeError, match="closed"):
+        len(wf)
