@@ -561,9 +561,9 @@ def feature_reductions(lib, _ffi, SpectrumPlan, features, dev, n_frames=1 << 18)
                 plan.sync()
 
             def timed(fn):
-                fn()
+                warm_up_by_time(fn)
                 ts = []
-                for _ in range(5):
+                for _ in range(7):
                     t0 = time.perf_counter()
                     fn()
                     ts.append(time.perf_counter() - t0)

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kern
         __builtin_assume(tid >= 0 && tid < F4K_THREADS);
         const F4kAddr A = f4k_addr(tid);
         cf v[16];
+        SDRK_PHASE("load_window");
         {
             const __amdgpu_buffer_rsrc_t r = frame_rsrc(iq + f * frame_stride, F4K_N * 8);
 #pragma unroll
@@ -69,8 +70,10 @@ __global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kern
                 }
             }
         }
+        SDRK_PHASE("transform");
         f4k_transform(v, lds, tw256, tw4k, A, tid);
         __syncthreads();   // every thread is through its last exchange read: the buffer becomes the row
+        SDRK_PHASE("logpsd_row");
         // bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor)
         __amdgpu_buffer_rsrc_t w = frame_rsrc(out_db ? out_db + f * (size_t)F4K_N : nullptr, out_db ? F4K_N * 4 : 0);
 #pragma unroll
@@ -83,6 +86,7 @@ __global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kern
         __syncthreads();
         row_features_wg(row, F4K_N, prm, sh, stats + f * 16, thr ? thr + f : nullptr,
                         idx ? idx + f * (size_t)prm.max_peaks : nullptr, cnt ? cnt + f : nullptr);
+        SDRK_PHASE("loop_end");
         __syncthreads();   // row and scratch are overwritten by the next frame's first exchange
     }
 }

@@ -7,6 +7,14 @@
 
 #include <atomic>
 
+// SDRK_PHASE("name"): a comment in the generated assembly that tools/phase_budget.py cuts a kernel's instruction stream at
+// (builds with -DSDRK_PHASE_MARKS only: the memory clobber would otherwise fence the scheduler in the shipped code)
+#ifdef SDRK_PHASE_MARKS
+#define SDRK_PHASE(name) asm volatile("; SDRK_PHASE " name ::: "memory")
+#else
+#define SDRK_PHASE(name) do { } while (0)
+#endif
+
 namespace sdrk {
 
 enum Epilogue : int {

@@ -543,6 +543,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     RowFeatValues r;
     float xv[16];
+    SDRK_PHASE("row_pickup_zero_hist");
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int i = tid + RF_THREADS * j;
@@ -562,6 +563,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     // scan A: max (+ first argmax), sum of x, sum of p = max(10^(x/10), 1e-15), sum of the unclipped x (for mean ln p).
     // Bins under -150 dB are clipped by np.clip(p, 1e-15, None); a wave that holds none (every wave of an ordinary row)
     // takes the loop without the clip selects: su = sum of all its x, sc = 0.
+    SDRK_PHASE("scanA_max_sums_pow10");
     float mx = -INFINITY;
     int amx = 0x7fffffff, nclip = 0;
     double su = 0.0, sc = 0.0, sp = 0.0;      // unclipped x, clipped x, p
@@ -612,6 +614,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
             if (tid + RF_THREADS * j < n && !(v < -150.0f)) sp += (double)rf_pow10_tenth_f32(v - level);
         }
     }
+    SDRK_PHASE("scanA_wave_reduce_argmax");
     double sx = su + sc;
     // the wave's maximum (NaNs skipped, as a running `v > mx` does), then its first bin: bin i = 256 j + 64 wave +
     // lane, so the first set bit of the first non-empty ballot over j.  (A wave whose maximum stayed -inf has no
@@ -638,6 +641,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
         sh.d[wave * 3] = sx; sh.d[wave * 3 + 1] = sp; sh.d[wave * 3 + 2] = su;
     }
     __syncthreads();     // partials of scan A; the zeroed histogram
+    SDRK_PHASE("scanA_merge");
     rf_opaque(xv);       // (keeps the compiler from carrying scan A's float64 copies of the row into scan B)
     mx = sh.f[0]; amx = sh.i[0];
     for (int w = 1; w < 4; ++w)
@@ -652,6 +656,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     // scan B: central moments; occupied-band edges (thresholds in float32, as peak - float(drop) is) from wave
     // ballots — bin i = 256 j + 64 wave + lane, so the first / last set bit of the first / last non-empty ballot
     // is the wave's first / last index, kept in scalar registers; the histogram of the select
+    SDRK_PHASE("scanB_moments_edges_histogram");
     const float t3 = mx - 3.0f, t10 = mx - 10.0f, t20 = mx - 20.0f;
     // histogram coordinate t(v) = 16 v - 16 (mean - 64): one fma, monotone in v; bin = floor(clamp(t, 0, 2047))
     const float hoff = -RF_BINS_PER_DB * ((float)mean - (float)(RF_BINS / 2) / RF_BINS_PER_DB);
@@ -662,32 +667,37 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int i = tid + RF_THREADS * j;
-        const bool valid = i < n;
         const float v = xv[j];
-        if (valid) {
+        if (i < n) {
             const double dv = (double)v - mean, d2 = dv * dv;
             s2 += d2;
             s4 = fma(d2, d2, s4);
             atomicAdd(&sh.bins[bin_of(v)], 1u);
         }
-        const int i0 = RF_THREADS * j + 64 * wave;
-        const unsigned long long b20 = __ballot(valid && v >= t20);
-        if (b20) {
-            if (f20 == 0x7fffffff) f20 = i0 + __builtin_ctzll(b20);
-            l20 = i0 + 63 - __builtin_clzll(b20);
-            const unsigned long long b10 = __ballot(valid && v >= t10);
-            if (b10) {
-                if (f10 == 0x7fffffff) f10 = i0 + __builtin_ctzll(b10);
-                l10 = i0 + 63 - __builtin_clzll(b10);
-                const unsigned long long b3 = __ballot(valid && v >= t3);
-                if (b3) {
-                    if (f3 == 0x7fffffff) f3 = i0 + __builtin_ctzll(b3);
-                    l3 = i0 + 63 - __builtin_clzll(b3);
-                }
-            }
-        }
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    // Band edges: only the wave's FIRST and LAST bin at or above each threshold are wanted, and bin i = 256 j + 64 wave +
+    // lane grows with j — so look for the first non-empty ballot from j = 0 up and for the last from j = 15 down, and
+    // stop there (wave-uniform exits).  An ordinary row has bins within 20 dB of its peak in every 64-bin stretch: two
+    // compares per threshold instead of sixteen (round 4 took every ballot of every j: 48 compares and ~26 scalar
+    // instructions per j).  The sets are nested (within 3 dB => within 10 => within 20): a wave without a bin within
+    // 20 dB is done after its first sixteen compares.
+    auto edges = [&](float t, int& first, int& last) -> bool {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned long long b = __ballot(tid + RF_THREADS * j < n && xv[j] >= t);
+            if (b) { first = RF_THREADS * j + 64 * wave + __builtin_ctzll(b); break; }
+        }
+        if (first == 0x7fffffff) return false;
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            const unsigned long long b = __ballot(tid + RF_THREADS * j < n && xv[j] >= t);
+            if (b) { last = RF_THREADS * j + 64 * wave + 63 - __builtin_clzll(b); break; }
+        }
+        return true;
+    };
+    if (edges(t20, f20, l20) && edges(t10, f10, l10)) edges(t3, f3, l3);
+    SDRK_PHASE("scanB_wave_reduce_merge");
     s2 = rf_wave_scan_add(s2);
     s4 = rf_wave_scan_add(s4);
     if (lane == 63) {
@@ -708,6 +718,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     r.f3 = f3; r.l3 = l3; r.f10 = f10; r.l10 = l10; r.f20 = f20; r.l20 = l20;
 
     // order statistics sorted[r0], sorted[r1] (ascending) for numpy.percentile's linear interpolation
+    SDRK_PHASE("select_prefix_scan");
     const unsigned r0 = (unsigned)(prm.rank < 0 ? 0 : (prm.rank > n - 1 ? n - 1 : prm.rank));
     const unsigned r1 = r0 + 1 < (unsigned)n ? r0 + 1 : r0;
     unsigned c[8];
@@ -745,6 +756,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     // the histogram path needs finite values (NaN / inf have no bin order) and target bins inside the window
     const double finite_probe = sum_x - sum_x;                           // 0 unless a value was NaN or +-inf
     bool fast = __builtin_amdgcn_readfirstlane((int)(finite_probe == 0.0)) && b0 >= 1 && b1 <= RF_BINS - 2;
+    SDRK_PHASE("select_candidates_rank");
     if (fast) {
         // bins b0 .. b1 (1 <= b0 <= b1 <= 2046; the bins between them are empty: ranks r0, r1 are adjacent) hold
         // exactly the values with b0 <= t(v) < b1 + 1
@@ -777,7 +789,9 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
             r.q1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), (int)__builtin_ctzll(m1 | (1ull << 63))));
         }
     }
+    SDRK_PHASE("select_fallback_radix");
     if (!fast) rf_select_pair(x, n, r0, sh, r.q0, r.q1, tid);
+    SDRK_PHASE("finish_threshold_stats_out");
     rf_finish(r, n, prm, sh, o_stats, o_thr, tid);      // (fast path: thread 0 is in wave 0, which holds q0 / q1)
     if (o_idx && o_cnt) {
         if (prm.min_distance >= 1 && prm.min_distance <= 16) rf_peaks_small(xv, x, n, prm, sh, o_idx, o_cnt, tid);
@@ -828,6 +842,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int d = prm.min_distance;
     // v > thr (float64 threshold) <=> v > the largest float32 <= thr: one float compare per bin
+    SDRK_PHASE("peaks_candidates_ballots");
     float thr_f = (float)sh.thr;
     if ((double)thr_f > sh.thr) thr_f = nextafterf(thr_f, -INFINITY);
     // candidates: strict local maxima above the threshold; word 4 j + wave holds bins 256 j + 64 wave + lane
@@ -844,6 +859,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
     }
     __syncthreads();
     // (1) exit-state tables: wave k owns words 16 k .. 16 k + 15
+    SDRK_PHASE("peaks_exit_state_tables");
     const int st = lane & 15, grp = lane >> 4;
 #pragma unroll 1
     for (int round = 0; round < 4; ++round) {
@@ -867,6 +883,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
     __syncthreads();
     if (wave == 0) {
         // (2) the walk: entry state of every word
+        SDRK_PHASE("peaks_walk_wave0");
         const unsigned long long mine = sh.tbl[lane];
         const int t_lo = (int)(unsigned)mine, t_hi = (int)(unsigned)(mine >> 32);
         // (scalar: the entry states collect as nibbles of eight scalar words; each lane then picks its own)
@@ -884,6 +901,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
         for (int k = 1; k < 8; ++k) mine_ent = (lane >> 3) == k ? ent[k] : mine_ent;
         const int entry = (int)((mine_ent >> (4 * (lane & 7))) & 15u);
         // (3) replay word `lane` from its entry state; indices out in order
+        SDRK_PHASE("peaks_replay_emit_wave0");
         const unsigned long long m = sh.flags[lane];
         unsigned alo, ahi;
         int last;
