@@ -49,6 +49,7 @@ struct LaunchArgs {
     float* d_mip = nullptr;
 };
 
+#ifdef __HIPCC__   // device helpers (the host-only sanitizer build of sdrk_api.hip, tests/fake_hip, compiles this header with g++)
 // 20*log10(sqrt(re^2+im^2) + eps), the expression order of streamer.py:121:
 // |X| first, then the additive floor, then the log.  v_sqrt_f32 / v_log_f32 are
 // 1-ulp approximations; the result is within ~2e-5 dB of numpy's float32 path
@@ -67,6 +68,8 @@ __device__ __forceinline__ float logpsd_db(float re, float im, float eps) {
 __device__ __forceinline__ float logpsd_db_fast(float p) {
     return __builtin_amdgcn_logf(p) * 3.01029995663981195213f;  // log2 -> 10*log10
 }
+
+#endif  // __HIPCC__
 
 // Kernels that need more than 64 KiB of dynamic LDS must opt in with hipFuncSetAttribute, which acts on
 // the CURRENT device's function object: a process that drives several GPUs (sharding.py, channels.py)

@@ -562,12 +562,11 @@ int exec_host_common(sdrk_plan* p, const void* iq, size_t n_frames, size_t frame
         if (poll_ok && p->h_small_flag) {
             const uint32_t seq = ++p->small_seq;
             if (hipStreamWriteValue32(p->stream, p->d_small_flag, seq, 0) == hipSuccess) {
-                volatile uint32_t* flag = p->h_small_flag;
+                const uint32_t* flag = p->h_small_flag;
                 for (int spins = 0; spins < 200000; ++spins) {
-                    if (*flag == seq) { done = true; break; }
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { done = true; break; }   // (a plain mov on x86: the acquire only binds the compiler)
                     __builtin_ia32_pause();
                 }
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
             } else {
                 (void)hipGetLastError();
             }
