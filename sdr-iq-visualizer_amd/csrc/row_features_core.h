@@ -495,9 +495,9 @@ __device__ __forceinline__ void rf_large(RowPtr x, int n, const RowFeatParams& p
     int f3 = 0x7fffffff, l3 = -1, f10 = 0x7fffffff, l10 = -1, f20 = 0x7fffffff, l20 = -1;
     for (int i = tid; i < n; i += RF_THREADS) {
         const float v = x[i];
-        const double dv = (double)v - mean, d2 = dv * dv;
+        const double dv = (double)v - mean, d2 = rf_mul_f64(dv, dv);   // (as in rf_small: one product, one sum, one written-out fma)
         s2 += d2;
-        s4 += d2 * d2;
+        s4 = fma(d2, d2, s4);
         if (v >= t3) { f3 = min(f3, i); l3 = max(l3, i); }
         if (v >= t10) { f10 = min(f10, i); l10 = max(l10, i); }
         if (v >= t20) { f20 = min(f20, i); l20 = max(l20, i); }
@@ -669,7 +669,10 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
         const int i = tid + RF_THREADS * j;
         const float v = xv[j];
         if (i < n) {
-            const double dv = (double)v - mean, d2 = dv * dv;
+            // (d2 as a product of its own, never contracted into `s2 += dv * dv`: the compiler's choice differed between the
+            //  fused and the stand-alone build of this very loop once the code around it changed — the last ulp of the
+            //  variance in 4 % of the rows; the fourth moment's fma is written out)
+            const double dv = (double)v - mean, d2 = rf_mul_f64(dv, dv);
             s2 += d2;
             s4 = fma(d2, d2, s4);
             atomicAdd(&sh.bins[bin_of(v)], 1u);

@@ -1760,13 +1760,13 @@ def test_scratch_placement_tuning_keeps_results_and_reports_probes(pkg):
             # the present scratch by one per cent
             rep = plan.last_placement
             assert rep["candidates_tried"] == 4 and rep["warmup_ms"] >= 55.0 and rep["warmup_launches"] >= 2
-            assert rep["first_ms"] == pytest.approx(probe[0], rel=1e-6) and rep["retimed_first_ms"] > 0
+            assert rep["first_ms"] == pytest.approx(probe[0], abs=1e-4) and rep["retimed_first_ms"] > 0
             ref0 = min(rep["first_ms"], rep["retimed_first_ms"])
             if chosen == 0:
-                assert all(v >= 0.99 * ref0 * (1 - 1e-6) for v in probe[1:])
+                assert all(v >= 0.99 * ref0 * (1 - 1e-3) for v in probe[1:])
             else:
-                assert probe[chosen] == min(probe[1:]) and probe[chosen] < 0.99 * ref0 * (1 + 1e-6)
-                assert rep["chosen_ms"] == pytest.approx(probe[chosen], rel=1e-6) and rep["gain_vs_retimed_first"] > 0
+                assert probe[chosen] == min(probe[1:]) and probe[chosen] < 0.99 * ref0 * (1 + 1e-3)
+                assert rep["chosen_ms"] == pytest.approx(probe[chosen], abs=1e-4) and rep["gain_vs_retimed_first"] > 0
             # warm, the two timings of the same scratch agree far better than round 4's first-to-last spread of 15 %
             assert abs(rep["first_ms"] - rep["retimed_first_ms"]) < 0.05 * ref0, rep
             plan.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)

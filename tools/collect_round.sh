@@ -5,7 +5,7 @@
 #    the placement probes and N bench processes with and without placement tuning.
 # SDRK_COLLECT_LIGHT=1: what changed or is quoted this round only — skips the placement micro-probes, the fused-vs-tiled and
 # overlap A/B runs (closed experiments: their logs of the round that ran them stand) and halves the bench-process counts.
-TAG=${1:-r04}
+TAG=${1:-r05}
 LIGHT=${SDRK_COLLECT_LIGHT:-0}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/collect_$TAG

@@ -5,7 +5,7 @@
 # MI355X guide prescribes) of the bench and of BASELINE configs 3 and 5.  Outputs under gpurun_out/prof_<tag>/;
 # tools/summarise_profiles.py turns them into the files committed under profiles/<tag>/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 LIGHT=${SDRK_COLLECT_LIGHT:-0}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -25,9 +25,13 @@ CFGS=("cfg3 65536 18749 32768 hann" "cfg5 1048576 256 1048576 hann" "n16384 1638
 [ "$LIGHT" = 1 ] && CFGS=("cfg3 65536 18749 32768 hann" "cfg5 1048576 256 1048576 hann")   # the BASELINE configs only
 for cfg in "${CFGS[@]}"; do
     set -- $cfg
-    run $1_trace --kernel-trace --stats --output-format csv -d "$OUT/$1_trace" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5
-    run $1_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/$1_fetch" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5
-    run $1_write --pmc WRITE_SIZE --output-format csv -d "$OUT/$1_write" -- python3 "$ROOT/tools/one_config.py" $2 $3 $4 $5
+    # (round 5: tools/cfg_steady.py instead of one_config.py — warmed up by time, transforms back to back as bench.py times
+    #  them; one_config.py's one warm-up + three isolated launches ran in the clock ramp after idle and gave kernel times
+    #  11-15 % above the event-timed step they were meant to explain)
+    run $1_trace --kernel-trace --stats --output-format csv -d "$OUT/$1_trace" -- python3 "$ROOT/tools/cfg_steady.py" $2 $3 $4 $5 --transforms 12 --out "$OUT/$1_steady.json"
+    python3 "$ROOT/tools/summarise_cfg_trace.py" "$OUT/$1_trace" "$OUT/$1_steady.json" > "$OUT/$1_trace_vs_events.json" 2>> "$OUT/summary.err"
+    run $1_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/$1_fetch" -- python3 "$ROOT/tools/cfg_steady.py" $2 $3 $4 $5 --transforms 4 --warm-ms 40
+    run $1_write --pmc WRITE_SIZE --output-format csv -d "$OUT/$1_write" -- python3 "$ROOT/tools/cfg_steady.py" $2 $3 $4 $5 --transforms 4 --warm-ms 40
 done
 # the per-row reductions: kernel trace + SQ instruction / activity counters, separate passes
 run feat_trace --kernel-trace --stats --output-format csv -d "$OUT/feat_trace" -- python3 "$ROOT/tools/feat_probe.py"
