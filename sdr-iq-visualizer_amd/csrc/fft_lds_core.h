@@ -67,6 +67,16 @@ __device__ __forceinline__ void lds_tw_init(LdsTw<LOG2N>& tw, const float2* __re
     }
 }
 
+// compiler fence beside the wave barriers of the barrier-free exchanges (SDRK_WAVE_SYNC_CLOBBER=0 in A/B builds: round 4's form)
+#ifndef SDRK_WAVE_SYNC_CLOBBER
+#define SDRK_WAVE_SYNC_CLOBBER 1
+#endif
+#if SDRK_WAVE_SYNC_CLOBBER
+#define SDRK_WAVE_SYNC_FENCE() asm volatile("" ::: "memory")
+#else
+#define SDRK_WAVE_SYNC_FENCE() do { } while (0)
+#endif
+
 // Workgroup barrier of the transform.  RAW = false: __syncthreads().  RAW = true: wait for this wave's own LDS
 // operations only, then s_barrier — for callers that keep an LDS-DMA (`buffer_load ... lds`) in flight across the
 // transform into a DIFFERENT part of LDS: __syncthreads() would make hipcc wait vmcnt(0) at every barrier and
@@ -76,7 +86,11 @@ __device__ __forceinline__ void lds_tw_init(LdsTw<LOG2N>& tw, const float2* __re
 template <int SYNC>
 __device__ __forceinline__ void lds_core_barrier() {
     if (SYNC == 2) {
+        // (the intrinsic is a scheduling barrier with side effects, not a memory clobber: the empty asm statements are what
+        //  forbids the compiler to move one lane's LDS store below — or its next LDS load above — the other lanes' exchange)
+        SDRK_WAVE_SYNC_FENCE();
         __builtin_amdgcn_wave_barrier();
+        SDRK_WAVE_SYNC_FENCE();
     } else if (SYNC == 1) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); vmcnt and expcnt untouched
@@ -173,7 +187,11 @@ __device__ __forceinline__ void lds_fft_core(cf (&v)[16], float2* __restrict__ l
 // 16384 at 256 / 512 lanes with the next frame prefetched into the spare registers — was built and measured in round 4:
 // parity-green and 15 / 25 % SLOWER than the 512 / 1024-thread kernels, 0.340 against 0.296 and 0.44 against 0.352 ms per
 // 2^27 samples.  Half the waves hide half the latency; the barrier-free case is the one that pays.)
-__device__ __forceinline__ void nv2_sync() { __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ void nv2_sync() {
+    SDRK_WAVE_SYNC_FENCE();                  // (see lds_core_barrier<2>)
+    __builtin_amdgcn_wave_barrier();
+    SDRK_WAVE_SYNC_FENCE();
+}
 
 template <int LOG2N>
 __device__ __forceinline__ LdsTw<LOG2N> nv2_tw_b(const LdsTw<LOG2N>& twa) {

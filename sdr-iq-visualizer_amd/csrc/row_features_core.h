@@ -572,6 +572,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     for (int j = 0; j < 16; ++j) vmin = fminf(vmin, tid + RF_THREADS * j < n ? xv[j] : INFINITY);
     const bool careful = __any(!(vmin > -149.0f));
     if (!careful) {
+        SDRK_PHASE("scanA_sums_ordinary_row");
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = tid + RF_THREADS * j;
@@ -584,6 +585,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four elements in flight at a time (register pressure)
         }
     } else {
+        SDRK_PHASE("scanA_sums_RARE_bins_under_minus_150dB");
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = tid + RF_THREADS * j;
@@ -604,8 +606,10 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     // Values past 300 dB (|X| > 1e15): float32 overflows 10^(x/10) at 385 dB where the reference's float64 does not.
     // Such a wave (none of any real row) sums p once more, relative to its own maximum, and scales the sum back in
     // float64 below.
+    SDRK_PHASE("scanA_level_check");
     float level = 0.0f;
     if (__any(mx > 300.0f)) {
+        SDRK_PHASE("scanA_RARE_values_over_300dB");
         level = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rf_wave_scan_max(mx)), 63));
         sp = 0.0;
 #pragma unroll
@@ -685,6 +689,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     // compares per threshold instead of sixteen (round 4 took every ballot of every j: 48 compares and ~26 scalar
     // instructions per j).  The sets are nested (within 3 dB => within 10 => within 20): a wave without a bin within
     // 20 dB is done after its first sixteen compares.
+    SDRK_PHASE("scanB_band_edges_first_last_search");
     auto edges = [&](float t, int& first, int& last) -> bool {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {

@@ -217,7 +217,7 @@ def frame_features(samples, sample_rate: float, center_freq: float, *, window=No
                                                         planes.ctypes.data_as(c_void_p), idx.ctypes.data_as(c_void_p),
                                                         rows.ctypes.data_as(c_void_p) if rows is not None else None))
         res = _arrays_from_planes(planes, idx, True)
-        return (res, rows) if return_rows else res
+        return (res, rows[0] if one else rows) if return_rows else res     # rows of ONE frame come back as (N,), as in the dict form
     stats, thr, idx, cnt = _result_arrays(n_rows, max_peaks)
     with plan._lock:
         check(lib().sdrk_frame_features_host(plan.handle, x.ctypes.data_as(c_void_p), ctypes.c_size_t(n_rows),

@@ -881,6 +881,11 @@ def test_frame_features_rows_stay_on_device(pkg, n, window):
                                                                               np.float32(got[r]["noise_floor_db"]))
     one = features.frame_features(x[0], 1_000_000, 2_400_000_000, window=window)
     _features_equal(one, got[0])
+    # one frame (N,) in: one result and its row (N,) out, in the dict form and in the array form alike
+    d1, r1 = features.frame_features(x[0], 1_000_000, 2_400_000_000, window=window, return_rows=True)
+    a1, r2 = features.frame_features(x[0], 1_000_000, 2_400_000_000, window=window, return_rows=True, as_arrays=True)
+    assert r1.shape == (n,) and r2.shape == (n,) and np.array_equal(r1, rows[0]) and np.array_equal(r2, rows[0])
+    assert a1["max_db"].shape == (1,) and a1["max_db"][0] == d1["max_db"]
 
 
 def test_frame_features_randomised_kinds(pkg):
