@@ -50,7 +50,7 @@ def host_boundary(quick):
     return out
 
 
-def device_run(nfft, n_frames, stride, window, reps, label):
+def device_run(nfft, n_frames, stride, window, reps, label, warm_ms=100.0):
     lib = _ffi.lib()
     in_samples = (n_frames - 1) * stride + nfft
     d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
@@ -65,8 +65,12 @@ def device_run(nfft, n_frames, stride, window, reps, label):
         with SpectrumPlan(nfft, window=window) as plan:
             plan.exec_device(d_gen.value, n_frames, d_out.value, frame_stride=stride)
             plan.sync()
-            ms = sorted(plan.exec_device_timed(d_gen.value, n_frames, d_out.value, 1, frame_stride=stride)
-                        for _ in range(reps))
+            # warm up BY TIME (round 5): an idle MI355X needs tens of milliseconds of load to reach its sustained shader clock;
+            # one warm-up launch + a few isolated ones measured the ramp (config 5: 1.58 ms here against 1.35 ms warm)
+            t0 = time.perf_counter()
+            while (time.perf_counter() - t0) * 1e3 < warm_ms:
+                plan.exec_device_timed(d_gen.value, n_frames, d_out.value, 4, frame_stride=stride)
+            ms = sorted(plan.exec_device_timed_each(d_gen.value, n_frames, d_out.value, max(reps, 5), frame_stride=stride))
         _ffi.check(lib.sdrk_dev_free(0, d_gen))
         t = ms[len(ms) // 2] * 1e-3
         algo = 8 * in_samples + 4 * n_frames * nfft
