@@ -14,6 +14,10 @@ cd "$ROOT"
 echo "== bench (full line)"; python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "== profiles"; bash tools/profile_round.sh $TAG > "$OUT/profile_round.log" 2>&1; cp gpurun_out/prof_$TAG/summary.json "$OUT/rocprof_summary.json"; cp gpurun_out/prof_$TAG/pmc_fetch_write_rows.csv "$OUT/" 2>/dev/null
 for t in bench cfg3 cfg5 n16384 n2p21 n2p22 feat; do cp gpurun_out/prof_$TAG/${t}_trace/*/*kernel_stats.csv "$OUT/${t}_kernel_stats.csv" 2>/dev/null; done
+cp gpurun_out/prof_$TAG/cfg3_trace_vs_events.json gpurun_out/prof_$TAG/cfg5_trace_vs_events.json gpurun_out/prof_$TAG/cfg3_steady.json gpurun_out/prof_$TAG/cfg5_steady.json "$OUT/" 2>/dev/null
+echo "== the continuous channel (config 5 as worded), kernel-traced"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/channel_trace" -- python3 "$ROOT/tools/channel_probe.py" --batch 24 > "$OUT/channel_probe.json" 2> /dev/null )
+python3 tools/summarise_channel_trace.py "$OUT/channel_trace" --batches 11 --runs 6 > "$OUT/channel_trace_summary.json" 2>/dev/null; cp "$OUT"/channel_trace/*/*kernel_stats.csv "$OUT/channel_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/channel_trace"
 echo "== size sweep"; python3 tools/size_sweep.py > "$OUT/size_sweep.log" 2>&1
 if [ "$LIGHT" != 1 ]; then
 echo "== placement probes"
@@ -70,5 +74,7 @@ echo "== bench.py under torch.distributed.run, one rank (the nccl group formed a
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 bench.py --gpus 1 --steps 5 --warmup 1 --no-secondary --cpu-seconds 0 > "$OUT/bench_torchrun1_nccl.json" 2> "$OUT/bench_torchrun1_nccl.err"; echo "rc=$? $(wc -l < "$OUT/bench_torchrun1_nccl.json") line(s)"
 echo "== bench.py --gpus 2, self-launched (rehearsal on one GPU: gloo rendezvous, ranks share the device)"
 python3 bench.py --gpus 2 --steps 3 --warmup 1 --frames 262144 --cpu-seconds 3 --cpu-all-cores-seconds 2 2> "$OUT/bench_gpus2_rehearsal.err" | grep '^{' > "$OUT/bench_gpus2_rehearsal.json"; echo "rc=$? $(wc -c < "$OUT/bench_gpus2_rehearsal.json") bytes"
+echo "== bench.py --gpus 4, self-launched on the one GPU (the control path of configs[3] / [4]; the -m gpu suite runs the same)"
+python3 bench.py --gpus 4 --steps 3 --warmup 1 --frames 65536 --first-frame 3145728 --cpu-seconds 0 --placement-candidates 1 2> "$OUT/bench_gpus4_rehearsal.err" | grep '^{' > "$OUT/bench_gpus4_rehearsal.json"; echo "rc=$? $(wc -c < "$OUT/bench_gpus4_rehearsal.json") bytes"
 echo "== one-frame host call"; python3 tools/small_call_probe.py > "$OUT/small_call_probe.log" 2>&1; cat "$OUT/small_call_probe.log"
 echo "== gpu tests"; python3 -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -2 "$OUT/pytest_gpu.log"
