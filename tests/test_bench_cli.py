@@ -20,7 +20,8 @@ def _args(argv):
 
 
 def test_child_command_is_the_drivers_launch_line():
-    a = _args(["--gpus", "4", "--steps", "7", "--warmup", "2", "--frames", "4096", "--window", "rect", "--no-secondary"])
+    a = _args(["--gpus", "4", "--steps", "7", "--warmup", "2", "--frames", "4096", "--window", "rect", "--no-secondary",
+               "--first-frame", "3145728"])
     cmd = bench.child_command(a, 29511)
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
@@ -28,7 +29,8 @@ def test_child_command_is_the_drivers_launch_line():
     assert cmd[cmd.index("--master-port") + 1] == "29511"
     script = cmd.index(os.path.abspath(bench.__file__))
     tail = cmd[script + 1:]
-    for flag, val in (("--gpus", "4"), ("--steps", "7"), ("--warmup", "2"), ("--frames", "4096"), ("--window", "rect")):
+    for flag, val in (("--gpus", "4"), ("--steps", "7"), ("--warmup", "2"), ("--frames", "4096"), ("--window", "rect"),
+                      ("--first-frame", "3145728")):                       # the ranks' frame ranges start where the parent was told
         assert tail[tail.index(flag) + 1] == val
     assert tail[tail.index("--cpu-seconds") + 1] == "0"        # the parent owns the CPU baseline
     assert "--no-secondary" in tail

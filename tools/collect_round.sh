@@ -11,6 +11,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/collect_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
+# SDRK_COLLECT_PART=A: the bench line, the rocprofv3 evidence, the channel trace, the size sweep; =B: everything after that.
+# (One gpurun call is limited to 20 minutes; the two parts are two calls.  Unset: both.)
+PART=${SDRK_COLLECT_PART:-AB}
+case $PART in *A*)
 echo "== bench (full line)"; python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "== profiles"; bash tools/profile_round.sh $TAG > "$OUT/profile_round.log" 2>&1; cp gpurun_out/prof_$TAG/summary.json "$OUT/rocprof_summary.json"; cp gpurun_out/prof_$TAG/pmc_fetch_write_rows.csv "$OUT/" 2>/dev/null
 for t in bench cfg3 cfg5 n16384 n2p21 n2p22 feat; do cp gpurun_out/prof_$TAG/${t}_trace/*/*kernel_stats.csv "$OUT/${t}_kernel_stats.csv" 2>/dev/null; done
@@ -19,6 +23,8 @@ echo "== the continuous channel (config 5 as worded), kernel-traced"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/channel_trace" -- python3 "$ROOT/tools/channel_probe.py" --batch 24 > "$OUT/channel_probe.json" 2> /dev/null )
 python3 tools/summarise_channel_trace.py "$OUT/channel_trace" --batches 11 --runs 6 > "$OUT/channel_trace_summary.json" 2>/dev/null; cp "$OUT"/channel_trace/*/*kernel_stats.csv "$OUT/channel_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/channel_trace"
 echo "== size sweep"; python3 tools/size_sweep.py > "$OUT/size_sweep.log" 2>&1
+;; esac
+case $PART in *B*) ;; *) exit 0;; esac
 if [ "$LIGHT" != 1 ]; then
 echo "== placement probes"
 mkdir -p sdr-iq-visualizer_amd/build_tools
