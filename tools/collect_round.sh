@@ -37,7 +37,7 @@ summ() { python3 -c "
 import json,sys
 l=json.loads(sys.stdin.read()); t=l['telemetry']
 print('%.4f  %.4f  %.4f  %.4f  %7.1f  %.4f  sclk_after %s  probe_ms %s chosen %d' % (l['launch_ms']['median'], l['launch_ms']['min'], l['launch_ms']['max'], l['roofline']['frac'], l['roofline']['measured_copy_GBps'], l['roofline']['frac_of_measured_copy'], t['after']['sclk_mhz'], l['placement']['probe_ms'], l['placement']['chosen']))"; }
-{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   ($NP processes; placement: 6 candidates)";
+{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   ($NP processes; placement: 10 candidates)";
   echo "# launch_ms median  min  max  frac_of_8TB/s  copy_GB/s  kernel/copy";
   for i in $(seq $NP); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 2>/dev/null | tail -1 | summ; done; } > "$OUT/placement_runs.txt"
 { echo "# the same with --placement-candidates 1 (plain alloc(in); alloc(out)), $NQ processes";
