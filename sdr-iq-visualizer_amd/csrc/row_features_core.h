@@ -536,6 +536,14 @@ __device__ __forceinline__ void rf_large(RowPtr x, int n, const RowFeatParams& p
 
 // Rows of up to 16 values per thread (n <= 4096: the reference's frame length and below): the row is read once
 // more into registers, and nothing after that reads it again except the neighbour compares of the peak scan.
+// TIMING-ONLY knock-outs for tools/f1_knockout.sh (results are WRONG with any bit set; the shipped build has 0): what a phase
+// costs = the time that disappears when it does.  1 = scan A's 10^(x/10) and float64 sums, 2 = scan B's float64 moments,
+// 4 = the histogram select (atomics, prefix scan, candidate rank), 8 = the band edges, 32 = the peak scan's exit-state tables,
+// 64 = its walk and replay (wave 0).  ("peaks off" — candidates too — is d_idx = NULL at run time.)
+#ifndef SDRK_F1_SKIP
+#define SDRK_F1_SKIP 0
+#endif
+
 template <class RowPtr>
 __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& prm, RowFeatShared& sh,
                                          double* __restrict__ o_stats, double* __restrict__ o_thr,
@@ -579,8 +587,10 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
             if (i < n) {
                 const float v = xv[j];
                 mx = fmaxf(mx, v);
-                su += (double)v;
-                sp += (double)rf_pow10_tenth_f32_inrange(v);
+                if (!(SDRK_F1_SKIP & 1)) {
+                    su += (double)v;
+                    sp += (double)rf_pow10_tenth_f32_inrange(v);
+                }
             }
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four elements in flight at a time (register pressure)
         }
@@ -676,10 +686,12 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
             // (d2 as a product of its own, never contracted into `s2 += dv * dv`: the compiler's choice differed between the
             //  fused and the stand-alone build of this very loop once the code around it changed — the last ulp of the
             //  variance in 4 % of the rows; the fourth moment's fma is written out)
-            const double dv = (double)v - mean, d2 = rf_mul_f64(dv, dv);
-            s2 += d2;
-            s4 = fma(d2, d2, s4);
-            atomicAdd(&sh.bins[bin_of(v)], 1u);
+            if (!(SDRK_F1_SKIP & 2)) {
+                const double dv = (double)v - mean, d2 = rf_mul_f64(dv, dv);
+                s2 += d2;
+                s4 = fma(d2, d2, s4);
+            }
+            if (!(SDRK_F1_SKIP & 4)) atomicAdd(&sh.bins[bin_of(v)], 1u);
         }
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -704,7 +716,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
         }
         return true;
     };
-    if (edges(t20, f20, l20) && edges(t10, f10, l10)) edges(t3, f3, l3);
+    if (!(SDRK_F1_SKIP & 8) && edges(t20, f20, l20) && edges(t10, f10, l10)) edges(t3, f3, l3);
     SDRK_PHASE("scanB_wave_reduce_merge");
     s2 = rf_wave_scan_add(s2);
     s4 = rf_wave_scan_add(s4);
@@ -726,6 +738,9 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     r.f3 = f3; r.l3 = l3; r.f10 = f10; r.l10 = l10; r.f20 = f20; r.l20 = l20;
 
     // order statistics sorted[r0], sorted[r1] (ascending) for numpy.percentile's linear interpolation
+    if (SDRK_F1_SKIP & 4) {
+        r.q0 = r.q1 = mx;
+    } else {
     SDRK_PHASE("select_prefix_scan");
     const unsigned r0 = (unsigned)(prm.rank < 0 ? 0 : (prm.rank > n - 1 ? n - 1 : prm.rank));
     const unsigned r1 = r0 + 1 < (unsigned)n ? r0 + 1 : r0;
@@ -799,6 +814,7 @@ __device__ __forceinline__ void rf_small(RowPtr x, int n, const RowFeatParams& p
     }
     SDRK_PHASE("select_fallback_radix");
     if (!fast) rf_select_pair(x, n, r0, sh, r.q0, r.q1, tid);
+    }
     SDRK_PHASE("finish_threshold_stats_out");
     rf_finish(r, n, prm, sh, o_stats, o_thr, tid);      // (fast path: thread 0 is in wave 0, which holds q0 / q1)
     if (o_idx && o_cnt) {
@@ -870,7 +886,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
     SDRK_PHASE("peaks_exit_state_tables");
     const int st = lane & 15, grp = lane >> 4;
 #pragma unroll 1
-    for (int round = 0; round < 4; ++round) {
+    for (int round = 0; round < ((SDRK_F1_SKIP & 32) ? 0 : 4); ++round) {
         const int w = 16 * wave + 4 * round + grp;
         const unsigned long long m = sh.flags[w];
         unsigned alo, ahi;
@@ -889,7 +905,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
         if (st == 15) sh.tbl[w] = ((unsigned long long)hi << 32) | lo;
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && !(SDRK_F1_SKIP & 64)) {
         // (2) the walk: entry state of every word
         SDRK_PHASE("peaks_walk_wave0");
         const unsigned long long mine = sh.tbl[lane];
