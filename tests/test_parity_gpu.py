@@ -1835,11 +1835,41 @@ def test_waterfall_maxhold16_companion_rows(pkg, n, shift_rows):
         assert np.array_equal(full2[-1], row) and np.array_equal(full2[:-1], full[1:])
         assert np.array_equal(wf.as_array(decimate=256), full2.reshape(shift_rows, n // 256, 256).max(-1))
         assert np.array_equal(wf.as_array(max_rows=1, decimate=4096), row.reshape(1, n // 4096, 4096).max(-1))
-    if n == 1 << 20:                                                       # rectangular window, unshifted... the ring is always shifted; eps variant
+    if n == 1 << 20:                                                       # another eps, rectangular window
         with pkg.WaterfallBuffer(n, maxlen=2, eps=1e-10) as wf2:
             wf2.append_iq(x[:2])
             full = wf2.as_array()
             assert np.array_equal(wf2.as_array(decimate=512), full.reshape(2, n // 512, 512).max(-1))
+        # a caller's own plan in the overlapped-passes form (row pass of chunk i beside the col pass of chunk i + 1, halves of the
+        # scratch): the companion rows follow the chunks of that form too; 30 frames = more than two half-chunks of 12
+        import ctypes
+        from sdr_iq_visualizer_amd import _ffi
+        from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+        lib = _ffi.lib()
+        frames30 = 30
+        d_in = ctypes.c_void_p()
+        _ffi.check(lib.sdrk_dev_alloc(0, frames30 * n * 8, ctypes.byref(d_in)))
+        try:
+            _ffi.check(lib.sdrk_synth_fill(0, 77, 0, frames30 * n // 4096, 4096, d_in, None))
+            with SpectrumPlan(n, window="hann", overlap_passes=True) as po, SpectrumPlan(n, window="hann") as ps, \
+                    pkg.WaterfallBuffer(n, maxlen=frames30) as wf3:
+                _ffi.check(lib.sdrk_waterfall_append_iq_device(wf3._h(), po.handle, d_in, ctypes.c_size_t(frames30), ctypes.c_size_t(n)))
+                assert wf3.maxhold16_rows() == frames30
+                dec = wf3.as_array(decimate=256)
+                d_rows = ctypes.c_void_p()
+                _ffi.check(lib.sdrk_dev_alloc(0, frames30 * n * 4, ctypes.byref(d_rows)))
+                try:
+                    ps.exec_device(d_in.value, frames30, d_rows.value)
+                    ps.sync()
+                    row = np.empty(n, dtype=np.float32)
+                    for f in (0, 11, 12, 23, 24, 29):                      # both sides of the half-chunk boundaries
+                        _ffi.check(lib.sdrk_memcpy_d2h(0, row.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_rows.value + f * n * 4), n * 4))
+                        assert np.array_equal(dec[f], row.reshape(n // 256, 256).max(-1)), f
+                        assert np.array_equal(wf3.as_array()[f], row)
+                finally:
+                    lib.sdrk_dev_free(0, d_rows)
+        finally:
+            lib.sdrk_dev_free(0, d_in)
 
 
 def test_config5_row_pass_unshifted_rows(pkg):
