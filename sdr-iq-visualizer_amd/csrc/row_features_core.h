@@ -860,6 +860,41 @@ __device__ __forceinline__ void rf_accept_word(unsigned mlo, unsigned mhi, int d
     }
 }
 
+// The same for spacings d >= 11 — the reference's max(3, N // 300) from N = 3300 up, i.e. at its own frame length: a 32-bin
+// half then holds at most three accepted peaks (bins b, b + d, b + 2 d <= 31), so the two data-dependent loops become 3 + 3
+// straight-line steps of four instructions — no wave-wide `any`, no branch, no exec-mask juggling.  An exhausted mask stays
+// zero through the remaining steps: ffs(0) - 1 = -1 never raises `last`, and the span shifted by it clears nothing.
+template <bool ACC>
+__device__ __forceinline__ void rf_accept_word3(unsigned mlo, unsigned mhi, int d, unsigned& alo, unsigned& ahi, int& last) {
+    const unsigned dspan = (1u << d) - 1u;
+    alo = 0; ahi = 0;
+    int llo = -1, lhi = -1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int bit = __builtin_ffs((int)mlo) - 1;
+        if (ACC) alo |= mlo & (0u - mlo);
+        llo = max(llo, bit);
+        mlo &= ~(dspan << (bit & 31));
+    }
+    const int carry = max(llo + d - 32, 0);                // leading bins of the high half still suppressed (< 16)
+    mhi &= ~0u << carry;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int bit = __builtin_ffs((int)mhi) - 1;
+        if (ACC) ahi |= mhi & (0u - mhi);
+        lhi = max(lhi, bit);
+        mhi &= ~(dspan << (bit & 31));
+    }
+    last = lhi >= 0 ? 32 + lhi : llo;
+}
+
+// wave-uniform choice between the two (d is a kernel argument)
+template <bool ACC>
+__device__ __forceinline__ void rf_accept(unsigned mlo, unsigned mhi, int d, unsigned& alo, unsigned& ahi, int& last) {
+    if (d >= 11) rf_accept_word3<ACC>(mlo, mhi, d, alo, ahi, last);
+    else rf_accept_word<ACC>(mlo, mhi, d, alo, ahi, last);
+}
+
 template <class RowPtr>
 __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, int n, const RowFeatParams& prm,
                                                RowFeatShared& sh, int* __restrict__ o_idx, int* __restrict__ o_cnt, int tid) {
@@ -870,17 +905,31 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
     float thr_f = (float)sh.thr;
     if ((double)thr_f > sh.thr) thr_f = nextafterf(thr_f, -INFINITY);
     // candidates: strict local maxima above the threshold; word 4 j + wave holds bins 256 j + 64 wave + lane
+    // Both neighbours of every bin are fetched unconditionally, four bins at a time, and the three compares are combined
+    // without short-circuit.  (Written as `v > thr && v > x[i - 1] && v > x[i + 1]` the compiler made each `&&` a branch with
+    // its own row read and `s_waitcnt lgkmcnt(0)` behind it: thirty-two exposed LDS latencies per thread, 2.3 ns of the
+    // 21.6 ns per row — round 5's knock-out measurement.)  Indices are clamped into the row; the ends are masked out below.
+    unsigned flo = 0, fhi = 0;          // lane j collects the ballot of bins 256 j + 64 wave ..., written once below
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int i = tid + RF_THREADS * j;
-        bool cand = false;
-        if (i >= 1 && i < n - 1) {
-            const float v = xv[j];
-            cand = v > thr_f && v > x[i - 1] && v > x[i + 1];
+    for (int j0 = 0; j0 < 16; j0 += 4) {
+        float lft[4], rgt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + RF_THREADS * (j0 + q);
+            lft[q] = x[min(max(i - 1, 0), n - 1)];
+            rgt[q] = x[min(i + 1, n - 1)];
         }
-        const unsigned long long b = __ballot(cand);
-        if (lane == 0) sh.flags[4 * j + wave] = b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q, i = tid + RF_THREADS * j;
+            const float v = xv[j];
+            const bool cand = (i >= 1) & (i < n - 1) & (v > thr_f) & (v > lft[q]) & (v > rgt[q]);
+            const unsigned long long b = __ballot(cand);
+            flo = lane == j ? (unsigned)b : flo;          // (v_writelane through inline assembly saved a compare per ballot and lost a
+            fhi = lane == j ? (unsigned)(b >> 32) : fhi;  //  ballot in about one row of 5 000: no builtin for it in this clang, so selects)
+        }
     }
+    if (lane < 16) sh.flags[4 * lane + wave] = ((unsigned long long)fhi << 32) | flo;
     __syncthreads();
     // (1) exit-state tables: wave k owns words 16 k .. 16 k + 15
     SDRK_PHASE("peaks_exit_state_tables");
@@ -891,7 +940,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
         const unsigned long long m = sh.flags[w];
         unsigned alo, ahi;
         int last;
-        rf_accept_word<false>((unsigned)m & (~0u << st), (unsigned)(m >> 32), d, alo, ahi, last);
+        rf_accept<false>((unsigned)m & (~0u << st), (unsigned)(m >> 32), d, alo, ahi, last);
         // exit state: bins of the next word still inside the last accepted peak's span
         int ex = last + d - 64;
         ex = ex < 0 ? 0 : ex;
@@ -929,7 +978,7 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
         const unsigned long long m = sh.flags[lane];
         unsigned alo, ahi;
         int last;
-        rf_accept_word<true>((unsigned)m & (~0u << entry), (unsigned)(m >> 32), d, alo, ahi, last);
+        rf_accept<true>((unsigned)m & (~0u << entry), (unsigned)(m >> 32), d, alo, ahi, last);
         const unsigned pc = (unsigned)(__popc(alo) + __popc(ahi));
         const unsigned incl = rf_wave_scan_add(pc);
         unsigned pos = incl - pc;
