@@ -13,6 +13,14 @@ echo "== bench (full line)"; python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/be
   rocprofv3 --kernel-trace --stats --output-format csv -d "$P/bench_trace" -- python3 "$ROOT/bench.py" --no-secondary --cpu-seconds 0 > "$P/bench_trace.stdout" 2> "$P/bench_trace.stderr"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/bench_fetch" -- python3 "$ROOT/bench.py" $BENCH_SHORT > "$P/bench_fetch.stdout" 2> "$P/bench_fetch.stderr"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/bench_write" -- python3 "$ROOT/bench.py" $BENCH_SHORT > "$P/bench_write.stdout" 2> "$P/bench_write.stderr" )
+( cd /tmp && export TMPDIR=/tmp    # the per-row reductions again (they changed after the first take): trace + the SQ counter sets
+  for t in feat_trace feat_sq1 feat_sq2 feat_sq3 feat_sq4; do rm -rf "$P/$t"; done
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$P/feat_trace" -- python3 "$ROOT/tools/feat_probe.py" > "$P/feat_trace.stdout" 2> "$P/feat_trace.stderr"
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d "$P/feat_sq1" -- python3 "$ROOT/tools/feat_probe.py" > /dev/null 2> "$P/feat_sq1.stderr"
+  rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d "$P/feat_sq2" -- python3 "$ROOT/tools/feat_probe.py" > /dev/null 2> "$P/feat_sq2.stderr"
+  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY --output-format csv -d "$P/feat_sq3" -- python3 "$ROOT/tools/feat_probe.py" > /dev/null 2> "$P/feat_sq3.stderr"
+  rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$P/feat_sq4" -- python3 "$ROOT/tools/feat_probe.py" > /dev/null 2> "$P/feat_sq4.stderr" )
+cp "$P"/feat_trace/*/*kernel_stats.csv "$OUT/feat_kernel_stats.csv" 2>/dev/null
 python3 tools/summarise_profiles.py "$P" > "$P/summary.json" 2> "$P/summary.err"; cp "$P/summary.json" "$OUT/rocprof_summary.json"
 python3 tools/summarise_profiles.py "$P" --rows "$OUT/pmc_fetch_write_rows.csv" 2>> "$P/summary.err"
 cp "$P"/bench_trace/*/*kernel_stats.csv "$OUT/bench_kernel_stats.csv" 2>/dev/null
