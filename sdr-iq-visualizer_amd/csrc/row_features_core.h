@@ -957,22 +957,24 @@ __device__ __forceinline__ void rf_peaks_small(const float (&xv)[16], RowPtr x, 
     if (wave == 0 && !(SDRK_F1_SKIP & 64)) {
         // (2) the walk: entry state of every word
         SDRK_PHASE("peaks_walk_wave0");
-        const unsigned long long mine = sh.tbl[lane];
-        const int t_lo = (int)(unsigned)mine, t_hi = (int)(unsigned)(mine >> 32);
-        // (scalar: the entry states collect as nibbles of eight scalar words; each lane then picks its own)
-        unsigned ent[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        unsigned s = 0;                                    // nothing accepted before bin 0 (pk[0] = -d)
-#pragma unroll
-        for (int w = 0; w < 64; ++w) {
-            ent[w >> 3] |= s << (4 * (w & 7));
-            const unsigned long long T = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(t_hi, w) << 32) |
-                                         (unsigned)__builtin_amdgcn_readlane(t_lo, w);
-            s = (unsigned)(T >> (4 * s)) & 15u;
+        // Lane w needs the state in which word w is entered = table(w - 1)[entry(w - 1)], entry(0) = 0: a chain through all 64
+        // words.  But the greedy chains from different entry states merge quickly, so most tables are CONSTANT over the entry
+        // states that can occur (0 .. d - 1) — and a word behind a constant table knows its entry state without the chain.  Those
+        // resolve at once; the others wait for their predecessor, one hop per round (64 rounds in the worst case, one or two on
+        // real rows).  (Round 4 walked the tables serially on the scalar unit: 64 x 7 dependent instructions, ~2 000 cycles of one
+        // wave per row.)
+        const unsigned long long Tprev = lane ? sh.tbl[lane - 1] : 0ull;         // ("before word 0": a constant 0)
+        const unsigned long long maskd = d >= 16 ? ~0ull : ((1ull << (4 * d)) - 1ull);
+        const unsigned c0 = (unsigned)Tprev & 15u;
+        bool known = ((Tprev ^ (0x1111111111111111ull * c0)) & maskd) == 0ull;
+        int entry = (int)c0;
+        while (__any(!known)) {
+            const int pe = __shfl_up(entry, 1, 64), pk = __shfl_up((int)known, 1, 64);
+            if (!known && pk) {
+                entry = (int)((unsigned)(Tprev >> (4 * pe)) & 15u);
+                known = true;
+            }
         }
-        unsigned mine_ent = ent[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) mine_ent = (lane >> 3) == k ? ent[k] : mine_ent;
-        const int entry = (int)((mine_ent >> (4 * (lane & 7))) & 15u);
         // (3) replay word `lane` from its entry state; indices out in order
         SDRK_PHASE("peaks_replay_emit_wave0");
         const unsigned long long m = sh.flags[lane];
