@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/f1_knockout
 mkdir -p $OUT
 cd $ROOT
-for r in 1 2; do for v in base ko1 ko2 ko4 ko8 ko32 ko64 ko96; do
+for r in 1 2; do for v in base ko2 ko4 ko8 ko32 ko64 ko96; do
   lib=$ROOT/sdr-iq-visualizer_amd/lib_$v/libsdrk.so; [ $v = base ] && lib=$ROOT/sdr-iq-visualizer_amd/lib/libsdrk.so
   SDRK_LIB=$lib timeout -k 10 200 python3 tools/feat_probe.py > $OUT/${v}_$r.out 2> $OUT/${v}_$r.err
   echo "$v: $(grep warm $OUT/${v}_$r.out | sed 's/fused //; s/ ms,.*ns\/row//' | tr '\n' ' ')" | tee -a $OUT/log.txt
