@@ -1034,11 +1034,10 @@ __device__ __forceinline__ void rf_peaks(RowPtr x, int n, const RowFeatParams& p
 #pragma unroll 4
         for (int c = 0; c < 16; ++c) {
             const int i = sbase + 256 * c + tid;
-            bool cand = false;
-            if (i >= 1 && i < n - 1) {
-                const float v = x[i];
-                cand = (double)v > thr && v > x[i - 1] && v > x[i + 1];
-            }
+            // all three reads unconditionally (indices clamped into the row, the ends masked): as `… && v > x[i - 1] && v > x[i + 1]`
+            // each `&&` became a branch with its own read and a full wait behind it (see rf_peaks_small)
+            const float v = x[min(i, n - 1)], lft = x[min(max(i - 1, 0), n - 1)], rgt = x[min(i + 1, n - 1)];
+            const bool cand = (i >= 1) & (i < n - 1) & ((double)v > thr) & (v > lft) & (v > rgt);
             const unsigned long long b = __ballot(cand);
             if (lane == 0) sh.flags[4 * c + wave] = b;
         }
