@@ -97,14 +97,15 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
         }
         issue(x, f + step);
         if (HAS_WINDOW) {
+#if !F4K_WINREG
+            float win[16];
 #pragma unroll
-#if F4K_WINREG
-            for (int j = 0; j < 16; ++j) v[j] = v[j] * win[j];
-#else
-            for (int j = 0; j < 16; ++j) v[j] = v[j] * lds_win[tid + 256 * j];
+            for (int j = 0; j < 16; ++j) win[j] = lds_win[tid + 256 * j];
 #endif
+            f4k_transform<true>(v, lds, tw256, tw4k, A, tid, win);
+        } else {
+            f4k_transform(v, lds, tw256, tw4k, A, tid);
         }
-        f4k_transform(v, lds, tw256, tw4k, A, tid);
         // ---- epilogue + store: bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor) ----
         __amdgpu_buffer_rsrc_t w = frame_rsrc(
             static_cast<char*>(out_raw) + f * (size_t)(F4K_N * OUT_ELEM), F4K_N * OUT_ELEM);

@@ -75,12 +75,14 @@ __device__ __forceinline__ void pow_tree(cf w1, cf (&w)[16]) {
 // v[j] = x[tid + 256 j] on entry; on return X[tid + 256 k2] is in v[rev16(k2)].
 // Contains four workgroup barriers; the first one also protects the previous
 // call's exchange-2 reads, so calls may follow each other directly.
+// With WIN, v[j] is still to be multiplied by the window coefficient win[j] = w[tid + 256 j] (folded into pass 1, cplx.h).
+template <bool WIN = false>
 __device__ __forceinline__ void f4k_transform(cf (&v)[16], float2* __restrict__ lds,
                                               const float2* __restrict__ tw256,
                                               const float2* __restrict__ tw4k, const F4kAddr& A,
-                                              int tid) {
+                                              int tid, const float* __restrict__ win = nullptr) {
     // ---- pass 1: DFT-16 over n2, times W4096^(r k0) = tw4k[k0][n0] * tw256[k0][n1] ----
-    radix16(v);
+    radix16<WIN>(v, win);
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
         float2 wa = tw4k[16 * k + A.lo], wb = tw256[16 * k + A.hi];

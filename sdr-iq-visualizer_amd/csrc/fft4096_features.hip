@@ -11,6 +11,15 @@
 // (32 VGPRs) and the window read from L2 instead of a 16 KiB LDS copy: <= 128 VGPRs and 37 KiB of LDS, FOUR
 // workgroups per CU that fill each other's barrier waits (the flagship runs three).  After the last pass the
 // 16 KiB row replaces the exchange buffer in LDS, followed by the reduction scratch.
+// Complex arithmetic in the scalar form here (cplx.h): with four waves on a SIMD two plain float32 instructions of two waves
+// issue in the four cycles one packed instruction takes, so packing buys no throughput, and this kernel is issue-bound, not
+// chain-bound (measured: packed 19.1 ns per row, scalar 18.8; profiles/r05/packed_complex_ab.log).  Both forms do the same
+// float operations in the same order: the rows equal the flagship's bit for bit.
+#ifndef SDRK_F1_PACKED_CF
+#define SDRK_F1_PACKED_CF 0
+#endif
+#undef SDRK_PACKED_CF
+#define SDRK_PACKED_CF SDRK_F1_PACKED_CF
 #include "fft4096_core.h"
 #include "row_features_core.h"
 
@@ -62,16 +71,16 @@ __global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kern
                 const v2f t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, j * 2048, 2));
                 v[j] = cf{t.x, t.y};
             }
-            if (HAS_WINDOW) {
+        }
+        float win[16];
+        if (HAS_WINDOW) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwin, tid * 4, j * 1024, 0));
-                    v[j] = v[j] * w;
-                }
-            }
+            for (int j = 0; j < 16; ++j)
+                win[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwin, tid * 4, j * 1024, 0));
         }
         SDRK_PHASE("transform");
-        f4k_transform(v, lds, tw256, tw4k, A, tid);
+        if (HAS_WINDOW) f4k_transform<true>(v, lds, tw256, tw4k, A, tid, win);
+        else f4k_transform(v, lds, tw256, tw4k, A, tid);
         __syncthreads();   // every thread is through its last exchange read: the buffer becomes the row
         SDRK_PHASE("logpsd_row");
         // bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor)

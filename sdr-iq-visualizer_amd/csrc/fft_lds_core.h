@@ -29,14 +29,13 @@ __device__ __forceinline__ void small_bfly(cf (&v)[16], int base) {
     if (R == 2) bfly2(v[base], v[base + 1]);
     if (R == 4) bfly4(v[base], v[base + 1], v[base + 2], v[base + 3]);
     if (R == 8) {
-        constexpr float R2 = 0.70710678118654752440f;
         cf e0 = v[base], e1 = v[base + 2], e2 = v[base + 4], e3 = v[base + 6];
         cf o0 = v[base + 1], o1 = v[base + 3], o2 = v[base + 5], o3 = v[base + 7];
         bfly4(e0, e1, e2, e3);
         bfly4(o0, o1, o2, o3);
-        cf t1 = cf{(o1.x + o1.y) * R2, (o1.y - o1.x) * R2};
+        cf t1 = rot_m45(o1);
         cf t2 = mul_mi(o2);
-        cf t3 = cf{(o3.y - o3.x) * R2, -(o3.x + o3.y) * R2};
+        cf t3 = rot_m135(o3);
         v[base] = e0 + o0; v[base + 4] = e0 - o0;
         v[base + 1] = e1 + t1; v[base + 5] = e1 - t1;
         v[base + 2] = e2 + t2; v[base + 6] = e2 - t2;

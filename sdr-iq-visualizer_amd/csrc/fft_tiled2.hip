@@ -357,7 +357,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 51
     const float2* __restrict__ scratch, void* __restrict__ out_raw, size_t n_frames, int A,
     const float2* __restrict__ twM, float eps, int shift) {
     using C = LdsCfg<LOG2M>;
-    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, ROWS = 16, WGT = T * ROWS;
+    constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, ROWS = 16;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 16 rows x SLOT, reused for the transpose
     const int tid = threadIdx.x;
     const int fr = tid / T, rt = tid - fr * T;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 51
             __syncthreads();
             const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float*>(out_raw) + f * nfft + k3_0,
                                                          (unsigned)((nfft - k3_0) * 4));
-            // element e = tid + WGT i of the ROWS x M tile: row r = e % ROWS (lanes), km = e / ROWS = tid / ROWS + T i
+            // element e = tid + 16 T i of the ROWS x M tile: row r = e % ROWS (lanes), km = e / ROWS = tid / ROWS + T i
             const int r = tid & (ROWS - 1), km0 = tid / ROWS;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -409,12 +409,14 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 51
                 tile[(rt + T * (q ^ xor_q)) * (ROWS + 1) + fr] = make_float2(z.x, z.y);
             }
             __syncthreads();
-            float2* __restrict__ o = static_cast<float2*>(out_raw) + f * nfft + k3_0;
+            // (buffer stores like the log branch: sixteen unrolled 64-bit addresses cost this branch its fourth wave per SIMD)
+            const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float2*>(out_raw) + f * nfft + k3_0,
+                                                         (unsigned)((nfft - k3_0) * 8));
+            const int r = tid & (ROWS - 1), km0 = tid / ROWS;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int e = tid + WGT * i;
-                const int r = e & (ROWS - 1), km = e / ROWS;
-                o[(size_t)km * A + r] = tile[km * (ROWS + 1) + r];
+                const float2 val = tile[(km0 + T * i) * (ROWS + 1) + r];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, val), ro, (km0 * A + r) * 8, i * T * A * 8, 0);
             }
         }
         __syncthreads();  // tile reads done before the next item's exchanges

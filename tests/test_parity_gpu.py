@@ -1783,8 +1783,9 @@ def test_scratch_placement_tuning_keeps_results_and_reports_probes(pkg):
             else:
                 assert probe[chosen] == min(probe[1:]) and probe[chosen] < 0.99 * ref0 * (1 + 1e-3)
                 assert rep["chosen_ms"] == pytest.approx(probe[chosen], abs=1e-4) and rep["gain_vs_retimed_first"] > 0
-            # warm, the two timings of the same scratch agree far better than round 4's first-to-last spread of 15 %
-            assert abs(rep["first_ms"] - rep["retimed_first_ms"]) < 0.05 * ref0, rep
+            # warm, the two timings of the same scratch agree far better than round 4's first-to-last spread of 15 % (measured
+            # here: within 1 %; the bound leaves room for a box with neighbours)
+            assert abs(rep["first_ms"] - rep["retimed_first_ms"]) < 0.10 * ref0, rep
             plan.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)
             plan.sync()
             _ffi.check(lib.sdrk_memcpy_d2h(0, b.ctypes.data_as(ctypes.c_void_p), d_out, b.nbytes))

@@ -25,7 +25,7 @@ ap.add_argument("--kernel", default="fft4096_features_kernelILb1")
 ap.add_argument("--loops", action="store_true")
 ap.add_argument("--asm", default="/tmp/phase_budget.s")
 a = ap.parse_args()
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-ffp-contract=on",
        "-DSDRK_PHASE_MARKS", "-S", "--cuda-device-only", "-o", a.asm, os.path.join(CSRC, a.file)]
 r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
 if r.returncode != 0:

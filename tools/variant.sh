@@ -4,4 +4,4 @@
 set -e
 NAME=$1; FLAGS=$2
 cd "$(dirname "$0")/../sdr-iq-visualizer_amd/csrc"
-make -s -j8 OBJDIR=../build_$NAME LIB=../lib_$NAME/libsdrk.so CXXFLAGS="-O3 -std=c++17 -fPIC -fno-slp-vectorize -Wall -Wno-unused-function $FLAGS"
+make -s -j8 OBJDIR=../build_$NAME LIB=../lib_$NAME/libsdrk.so CXXFLAGS="-O3 -std=c++17 -fPIC -fno-slp-vectorize -ffp-contract=on -Wall -Wno-unused-function $FLAGS"
