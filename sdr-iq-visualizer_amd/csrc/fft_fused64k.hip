@@ -193,7 +193,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
             issue_from(f + 1, xb, 16 - SH);
             cf v[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = HAS_WINDOW ? cf{xa[q].x * wreg[q], xa[q].y * wreg[q]} : cf{xa[q].x, xa[q].y};
+            for (int q = 0; q < 16; ++q) v[q] = HAS_WINDOW ? cf{xa[q].x, xa[q].y} * wreg[q] : cf{xa[q].x, xa[q].y};
             lds_fft_core<8, 16>(v, lds_all, fr, tau, tw);
             // the ring slot must have been read by every row workgroup (frame s - D)
             if (s >= (unsigned)D && !wg_wait_all(row_done, s - D + 1, ctrl, 1, sh_role)) return;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
 #pragma unroll
                 for (int j = 0; j < R0; ++j) {
                     const int q = i + C0 * j;
-                    v[i * R0 + j] = HAS_WINDOW ? cf{xa[q].x * wreg[q], xa[q].y * wreg[q]} : cf{xa[q].x, xa[q].y};
+                    v[i * R0 + j] = HAS_WINDOW ? cf{xa[q].x, xa[q].y} * wreg[q] : cf{xa[q].x, xa[q].y};
                 }
             lds_fft_core<LOG2A, W>(v, lds_all, fr, tau, tw);
             store(f, m, v, bw);
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kerne
                 for (int j = 0; j < R0; ++j) {
                     const int q = i + C0 * j;
                     const float2 x = stage[(tau + T * q) * W + fr];
-                    v[i * R0 + j] = HAS_WINDOW ? cf{x.x * wreg[q], x.y * wreg[q]} : cf{x.x, x.y};
+                    v[i * R0 + j] = HAS_WINDOW ? cf{x.x, x.y} * wreg[q] : cf{x.x, x.y};
                 }
             lds_core_barrier<true>();                                      // every wave has picked its samples up
             dma(f + 1);
