@@ -20,7 +20,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // folds whole-vector negation and broadcasts into those modifiers by itself but not a one-lane negation (it emits v_xor + v_mov),
 // hence the few asm statements; they are plain VALU arithmetic (no lane crossing, interlocked by the hardware) and not volatile,
 // so the scheduler moves them like any other instruction.  Every form below performs the SAME float operations in the same
-// order as the scalar forms of the #else branch: the two builds are bit-identical (tests/test_parity_gpu.py).
+// order as the scalar forms of the #else branch: the two builds are bit-identical (tools/hash_outputs.py under both).
 // What it buys: one wave issues a VALU instruction every four cycles, packed or not, and a SIMD takes two plain float32
 // instructions of two different waves in those four cycles but one packed one (tools/pkprobe.hip, profiles/r05/pkprobe.log):
 // at three waves per SIMD a complex add costs 1.84 ns packed against 2 x 1.15 ns, and a wave's own dependent chain halves.
@@ -53,30 +53,8 @@ __device__ __forceinline__ cf cmul_k(cf a, float bx, float by) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "s"(b), "v"(m));
     return r;
 }
-// a * (-i) = (a.y, -a.x)
-__device__ __forceinline__ cf mul_mi(cf a) { return add_mi(cf{0.f, 0.f}, a); }
-// a * (1 - i) / sqrt2 = ((a.x + a.y) R2, (a.y - a.x) R2) ; a * (-1 - i) / sqrt2 = ((a.y - a.x) R2, -(a.x + a.y) R2)
-__device__ __forceinline__ cf rot_m45(cf a) { return add_mi(a, a) * 0.70710678118654752440f; }
-__device__ __forceinline__ cf rot_m135(cf a) { return add_pi(a, a) * -0.70710678118654752440f; }
 // s * k + a, one rounding per component (an explicit fused multiply-add: the build runs with -ffp-contract=on)
 __device__ __forceinline__ cf fma_s(cf s, float k, cf a) { return __builtin_elementwise_fma(s, cf{k, k}, a); }
-
-// 4-point forward DFT in place: (a,b,c,d) = inputs n=0..3 -> outputs k=0..3.
-__device__ __forceinline__ void bfly4(cf& a, cf& b, cf& c, cf& d) {
-    cf t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
-    a = t0 + t2;
-    c = t0 - t2;
-    b = add_mi(t1, t3);   // k=1: t1 + (-i) t3
-    d = add_pi(t1, t3);   // k=3: t1 + (+i) t3
-}
-// the same with input c still to be multiplied by -i (the W16^4 twiddle of radix16's second layer, folded into the sums)
-__device__ __forceinline__ void bfly4_c_mi(cf& a, cf& b, cf& c, cf& d) {
-    cf t0 = add_mi(a, c), t1 = add_pi(a, c), t2 = b + d, t3 = b - d;
-    a = t0 + t2;
-    c = t0 - t2;
-    b = add_mi(t1, t3);
-    d = add_pi(t1, t3);
-}
 #else
 struct cf {
     float x, y;
@@ -86,37 +64,23 @@ __device__ __forceinline__ cf mk(float x, float y) { return cf{x, y}; }
 __device__ __forceinline__ cf operator+(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cf operator-(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cf operator*(cf a, float s) { return cf{a.x * s, a.y * s}; }
-// a*b
+__device__ __forceinline__ cf add_mi(cf a, cf b) { return cf{a.x + b.y, a.y - b.x}; }
+__device__ __forceinline__ cf add_pi(cf a, cf b) { return cf{a.x - b.y, a.y + b.x}; }
 __device__ __forceinline__ cf cmul(cf a, cf b) {
     return cf{fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)};
 }
-// a * (-i) = (a.y, -a.x)
-__device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
-
-// 4-point forward DFT in place: (a,b,c,d) = inputs n=0..3 -> outputs k=0..3.
-__device__ __forceinline__ void bfly4(cf& a, cf& b, cf& c, cf& d) {
-    cf t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
-    a = t0 + t2;
-    c = t0 - t2;
-    // k=1: t1 + (-i) t3 ; k=3: t1 + (+i) t3
-    b = cf{t1.x + t3.y, t1.y - t3.x};
-    d = cf{t1.x - t3.y, t1.y + t3.x};
-}
 __device__ __forceinline__ cf cmul_k(cf a, float bx, float by) { return cmul(a, cf{bx, by}); }
-__device__ __forceinline__ cf rot_m45(cf a) {
-    constexpr float R2 = 0.70710678118654752440f;
-    return cf{(a.x + a.y) * R2, (a.y - a.x) * R2};
-}
-__device__ __forceinline__ cf rot_m135(cf a) {
-    constexpr float R2 = 0.70710678118654752440f;
-    return cf{(a.y - a.x) * R2, -(a.x + a.y) * R2};
-}
-__device__ __forceinline__ void bfly4_c_mi(cf& a, cf& b, cf& c, cf& d) {
-    c = mul_mi(c);
-    bfly4(a, b, c, d);
-}
 __device__ __forceinline__ cf fma_s(cf s, float k, cf a) { return cf{fmaf(s.x, k, a.x), fmaf(s.y, k, a.y)}; }
 #endif
+
+// a * (-i) = (a.y, -a.x)
+__device__ __forceinline__ cf mul_mi(cf a) { return add_mi(cf{0.f, 0.f}, a); }
+// (1 -+ i) a: a (1 - i) = (a.x + a.y, a.y - a.x) ; a (1 + i) = (a.x - a.y, a.y + a.x)
+__device__ __forceinline__ cf one_mi(cf a) { return add_mi(a, a); }
+__device__ __forceinline__ cf one_pi(cf a) { return add_pi(a, a); }
+// a * (1 - i) / sqrt2 ; a * (-1 - i) / sqrt2
+__device__ __forceinline__ cf rot_m45(cf a) { return one_mi(a) * 0.70710678118654752440f; }
+__device__ __forceinline__ cf rot_m135(cf a) { return one_pi(a) * -0.70710678118654752440f; }
 
 // the two sums of a radix-4 butterfly, t0 = a + c and t1 = a - c, with c = sc * k still unscaled: two fused multiply-adds
 __device__ __forceinline__ void sums_scaled(cf a, cf sc, float k, cf& t0, cf& t1) {
@@ -127,22 +91,11 @@ __device__ __forceinline__ void sums_scaled(cf a, cf sc, float k, cf& t0, cf& t1
 __device__ __forceinline__ void bfly4_finish(cf t0, cf t1, cf t2, cf t3, cf& a, cf& b, cf& c, cf& d) {
     a = t0 + t2;
     c = t0 - t2;
-#if SDRK_PACKED_CF
-    b = add_mi(t1, t3);
-    d = add_pi(t1, t3);
-#else
-    b = cf{t1.x + t3.y, t1.y - t3.x};
-    d = cf{t1.x - t3.y, t1.y + t3.x};
-#endif
+    b = add_mi(t1, t3);   // k=1: t1 + (-i) t3
+    d = add_pi(t1, t3);   // k=3: t1 + (+i) t3
 }
-// (1 -+ i) a, the unscaled halves of rot_m45 / rot_m135: a (1 - i) = (a.x + a.y, a.y - a.x) ; a (1 + i) = (a.x - a.y, a.y + a.x)
-#if SDRK_PACKED_CF
-__device__ __forceinline__ cf one_mi(cf a) { return add_mi(a, a); }
-__device__ __forceinline__ cf one_pi(cf a) { return add_pi(a, a); }
-#else
-__device__ __forceinline__ cf one_mi(cf a) { return cf{a.x + a.y, a.y - a.x}; }
-__device__ __forceinline__ cf one_pi(cf a) { return cf{a.x - a.y, a.y + a.x}; }
-#endif
+// 4-point forward DFT in place: (a,b,c,d) = inputs n=0..3 -> outputs k=0..3.
+__device__ __forceinline__ void bfly4(cf& a, cf& b, cf& c, cf& d) { bfly4_finish(a + c, a - c, b + d, b - d, a, b, c, d); }
 
 // 2-point DFT in place.
 __device__ __forceinline__ void bfly2(cf& a, cf& b) {
@@ -190,13 +143,8 @@ __device__ __forceinline__ void radix16(cf (&v)[16], const float* __restrict__ w
     t3 = v[5] - v[7];
     bfly4_finish(t0, t1, t2, t3, v[4], v[5], v[6], v[7]);
     // k2 = 2: slots 9,10,11 <- W^2, W^4 = -i, W^6 = (-1-i)/sqrt2
-#if SDRK_PACKED_CF
     t0 = add_mi(v[8], v[10]);
     t1 = add_pi(v[8], v[10]);
-#else
-    t0 = cf{v[8].x + v[10].y, v[8].y - v[10].x};
-    t1 = cf{v[8].x - v[10].y, v[8].y + v[10].x};
-#endif
     {
         const cf p9 = one_mi(v[9]) * R2, s11 = one_pi(v[11]);
         t2 = fma_s(s11, -R2, p9);
