@@ -65,20 +65,28 @@ __global__ __launch_bounds__(256) void blu_post_kernel(const float2* __restrict_
     }
 }
 
-// ---- fused form for M <= 16384: the pre-multiply rides on the loads of the first transform, the filter
-// multiply (+ conjugation) on its stores, and the post-multiply / fftshift / log on the stores of the second:
-// two passes over the data instead of five.
-template <int LOG2M>
-__global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_fwd_kernel(
+// ---- fused form for M <= 16384: the whole chirp-z of a frame in ONE kernel, one LDS residency.  The pre-multiply rides on
+// the loads of the first transform; its result X[tau + T q] is in the thread's own registers in exactly the index pattern the
+// next transform's input wants (x[tau + T (i + C0 j)] in slot i R0 + j), so the filter multiply (+ conjugation) and the hand-over
+// to the second transform are register moves — no exchange, no trip through HBM —; the post-multiply / fftshift / log ride on the
+// second transform's stores.  12 N bytes of HBM traffic per frame (the chirp and the filter spectrum come from L2) where the
+// two-kernel form of round 3 moved 12 N + 16 M and the five-pass form 12 N + 64 M.
+template <int LOG2M, int EPILOGUE>
+__global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_one_kernel(
     const float2* __restrict__ iq, size_t frame_stride, size_t n_frames, int N, const float* __restrict__ window,
-    const float2* __restrict__ chirp, const float2* __restrict__ bspec, const float2* __restrict__ twM,
-    float2* __restrict__ work) {
+    const float2* __restrict__ chirp, const float2* __restrict__ bspec, const float2* __restrict__ twM, float eps, int shift,
+    void* __restrict__ out_raw) {
     using C = LdsCfg<LOG2M>;
     constexpr int M = C::N, P = C::P, R0 = C::R0, T = C::T, F = C::F, C0 = 16 / R0;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
+    // the per-thread twiddle bases: constant over the frames, but at 1024 threads (128 registers) keeping them across the loop
+    // costs spills — there they are fetched again per frame (L2 hits) from the opaque thread number below
+    constexpr bool TW_PER_FRAME = C::WG >= 1024;
     LdsTw<LOG2M> tw;
-    lds_tw_init<LOG2M>(tw, twM, (int)threadIdx.x % T);
+    if (!TW_PER_FRAME) lds_tw_init<LOG2M>(tw, twM, (int)threadIdx.x % T);
     const size_t n_groups = (n_frames + F - 1) / F;
+    const float inv_m = 1.0f / (float)M;
+    const int rot = shift ? N / 2 : 0;
     for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         // (thread coordinates re-derived per group from an opaque copy of the thread number: hoisted out of this
         // persistent loop, the sixteen sample offsets and their `n < N` masks cost the registers the transform spills)
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_f
         asm volatile("" : "+v"(tid));
         __builtin_assume(tid >= 0 && tid < C::WG);
         const int fr = tid / T, tau = tid - fr * T;
+        if (TW_PER_FRAME) lds_tw_init<LOG2M>(tw, twM, tau);
         float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
         const size_t f = g * F + fr;
         const bool ok = f < n_frames;
@@ -106,55 +115,34 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_f
                 v[i * R0 + j] = a;
             }
         lds_fft_core<LOG2M, 1>(v, lds, 0, tau, tw);
-        if (ok) {
-            float2* __restrict__ o = work + f * (size_t)M;
+        // A[k] at k = tau + T q (k = q for the one-pass lengths) sits in v[rev16(q)]: C'[k] = conj(A[k] B[k]) goes to the slot
+        // that reads x[tau + T (i + C0 j)] with q = i + C0 j
+        // (in place, four at a time: sixteen filter values fetched at once cost the 1024-thread lengths their registers)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int k = P == 1 ? q : tau + T * q;
-                const cf a = v[rev16(q)];
-                const float2 b = bspec[k];
-                o[k] = make_float2(fmaf(a.x, b.x, -(a.y * b.y)), -fmaf(a.x, b.y, a.y * b.x));  // conj(a*b)
-            }
+        for (int q = 0; q < 16; ++q) {
+            const int k = P == 1 ? q : tau + T * q;
+            const cf a = v[rev16(q)];
+            const float2 b = bspec[k];
+            v[rev16(q)] = cf{fmaf(a.x, b.x, -(a.y * b.y)), -fmaf(a.x, b.y, a.y * b.x)};
+            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-    }
-}
-
-template <int LOG2M, int EPILOGUE>
-__global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_inv_kernel(
-    const float2* __restrict__ work, size_t n_frames, int N, const float2* __restrict__ chirp,
-    const float2* __restrict__ twM, float eps, int shift, void* __restrict__ out_raw) {
-    using C = LdsCfg<LOG2M>;
-    constexpr int M = C::N, P = C::P, R0 = C::R0, T = C::T, F = C::F, C0 = 16 / R0;
-    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
-    LdsTw<LOG2M> tw;
-    lds_tw_init<LOG2M>(tw, twM, (int)threadIdx.x % T);
-    const size_t n_groups = (n_frames + F - 1) / F;
-    const float inv_m = 1.0f / (float)M;
-    const int rot = shift ? N / 2 : 0;
-    for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        int tid = threadIdx.x;                                     // (as in blu_fwd_kernel)
-        asm volatile("" : "+v"(tid));
-        __builtin_assume(tid >= 0 && tid < C::WG);
-        const int fr = tid / T, tau = tid - fr * T;
-        float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
-        const size_t f = g * F + fr;
-        const bool ok = f < n_frames;
-        const float2* __restrict__ x = work + (ok ? f : 0) * (size_t)M;
-        cf v[16];
+        cf u[16];
 #pragma unroll
         for (int i = 0; i < C0; ++i)
 #pragma unroll
-            for (int j = 0; j < R0; ++j) {
-                const float2 s = x[tau + T * (i + C0 * j)];
-                v[i * R0 + j] = ok ? cf{s.x, s.y} : cf{0.f, 0.f};
-            }
-        lds_fft_core<LOG2M, 1>(v, lds, 0, tau, tw);
+            for (int j = 0; j < R0; ++j) u[i * R0 + j] = v[rev16(i + C0 * j)];
+        // (the second transform's exchange addresses are computed again from an opaque copy of the row index: kept from the first
+        // transform they would be sixteen more live registers across it)
+        int tau2 = tau;
+        asm volatile("" : "+v"(tau2));
+        __builtin_assume(tau2 >= 0 && tau2 < T);
+        lds_fft_core<LOG2M, 1>(u, lds, 0, tau2, tw);
         if (ok) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int k = P == 1 ? q : tau + T * q;
+                const int k = P == 1 ? q : tau2 + T * q;
                 if (k < N) {
-                    const cf y = v[rev16(q)];
+                    const cf y = u[rev16(q)];
                     const float2 c = chirp[k];
                     const float re = fmaf(c.x, y.x, -(c.y * y.y)) * inv_m;   // conj(c) * conj(y) = conj(c y)
                     const float im = -fmaf(c.x, y.y, c.y * y.x) * inv_m;
@@ -172,7 +160,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::WG, LdsCfg<LOG2M>::WAVES) void blu_i
 
 template <int LOG2M>
 static hipError_t blu_fused_n(const void* d_iq, size_t frame_stride, size_t n_frames, int N, const float* d_window,
-                              const void* d_chirp, const void* d_bspec, const void* d_twM, void* d_work, float eps,
+                              const void* d_chirp, const void* d_bspec, const void* d_twM, float eps,
                               int shift, int epilogue, void* d_out, int num_cus, hipStream_t s) {
     using C = LdsCfg<LOG2M>;
     const size_t lds_bytes = (size_t)C::F * C::SLOT * sizeof(float2);
@@ -182,33 +170,24 @@ static hipError_t blu_fused_n(const void* d_iq, size_t frame_stride, size_t n_fr
     if (per_cu < 1) per_cu = 1;
     const size_t n_groups = (n_frames + C::F - 1) / C::F, cap = (size_t)num_cus * per_cu;
     const unsigned grid = (unsigned)(n_groups < cap ? n_groups : cap);
-    auto fwd = blu_fwd_kernel<LOG2M>;
-    auto inv0 = blu_inv_kernel<LOG2M, EPI_LOGPSD>;
-    auto inv1 = blu_inv_kernel<LOG2M, EPI_COMPLEX>;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(inv0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(inv1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(fwd, dim3(grid), dim3(C::WG), lds_bytes, s, static_cast<const float2*>(d_iq), frame_stride, n_frames, N,
-                       d_window, static_cast<const float2*>(d_chirp), static_cast<const float2*>(d_bspec),
-                       static_cast<const float2*>(d_twM), static_cast<float2*>(d_work));
-    if (epilogue == EPI_LOGPSD)
-        hipLaunchKernelGGL(inv0, dim3(grid), dim3(C::WG), lds_bytes, s, static_cast<const float2*>(d_work), n_frames, N,
-                           static_cast<const float2*>(d_chirp), static_cast<const float2*>(d_twM), eps, shift, d_out);
-    else
-        hipLaunchKernelGGL(inv1, dim3(grid), dim3(C::WG), lds_bytes, s, static_cast<const float2*>(d_work), n_frames, N,
-                           static_cast<const float2*>(d_chirp), static_cast<const float2*>(d_twM), eps, shift, d_out);
+    auto k0 = blu_one_kernel<LOG2M, EPI_LOGPSD>;
+    auto k1 = blu_one_kernel<LOG2M, EPI_COMPLEX>;
+    static std::atomic<uint64_t> lds_set0{0}, lds_set1{0};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(epilogue == EPI_LOGPSD ? k0 : k1), lds_bytes,
+                                      epilogue == EPI_LOGPSD ? lds_set0 : lds_set1);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(epilogue == EPI_LOGPSD ? k0 : k1, dim3(grid), dim3(C::WG), lds_bytes, s, static_cast<const float2*>(d_iq),
+                       frame_stride, n_frames, N, d_window, static_cast<const float2*>(d_chirp),
+                       static_cast<const float2*>(d_bspec), static_cast<const float2*>(d_twM), eps, shift, d_out);
     return hipGetLastError();
 }
 
 bool blu_fused_supports(int M) { return M >= 16 && M <= 16384; }
 
 hipError_t launch_blu_fused(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
-                            const void* d_chirp, const void* d_bspec, const void* d_twM, void* d_work, float eps, int shift,
+                            const void* d_chirp, const void* d_bspec, const void* d_twM, float eps, int shift,
                             int epilogue, void* d_out, int num_cus, hipStream_t s) {
-#define BLU_CASE(L) case (1 << L): return blu_fused_n<L>(d_iq, frame_stride, n_frames, N, d_window, d_chirp, d_bspec, d_twM, d_work, eps, shift, epilogue, d_out, num_cus, s);
+#define BLU_CASE(L) case (1 << L): return blu_fused_n<L>(d_iq, frame_stride, n_frames, N, d_window, d_chirp, d_bspec, d_twM, eps, shift, epilogue, d_out, num_cus, s);
     switch (M) {
         BLU_CASE(4) BLU_CASE(5) BLU_CASE(6) BLU_CASE(7) BLU_CASE(8) BLU_CASE(9) BLU_CASE(10) BLU_CASE(11) BLU_CASE(12)
         BLU_CASE(13) BLU_CASE(14)

@@ -104,7 +104,7 @@ hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl);
 // arbitrary frame lengths (bluestein.hip)
 bool blu_fused_supports(int M);
 hipError_t launch_blu_fused(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
-                            const void* d_chirp, const void* d_bspec, const void* d_twM, void* d_work, float eps, int shift,
+                            const void* d_chirp, const void* d_bspec, const void* d_twM, float eps, int shift,
                             int epilogue, void* d_out, int num_cus, hipStream_t s);
 hipError_t launch_blu_pre(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
                           const void* d_chirp, void* d_a, int num_cus, hipStream_t s);

@@ -253,10 +253,10 @@ int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t fra
         const size_t out_elem = epilogue == sdrk::EPI_LOGPSD ? sizeof(float) : sizeof(float2);
         for (size_t f0 = 0; f0 < n_frames; f0 += p->blu_frames) {
             const size_t nf = n_frames - f0 < p->blu_frames ? n_frames - f0 : p->blu_frames;
-            if (sdrk::blu_fused_supports(M)) {   // two passes instead of five
+            if (sdrk::blu_fused_supports(M)) {   // one kernel, one pass over HBM, instead of five
                 e = sdrk::launch_blu_fused(static_cast<const float2*>(d_iq) + f0 * frame_stride, frame_stride, nf, N, M,
                                            p->d_window, p->d_blu_chirp, p->d_blu_bspec, p->blu_inner->d_twiddle,
-                                           p->d_blu_a, p->eps, p->shift, epilogue,
+                                           p->eps, p->shift, epilogue,
                                            static_cast<char*>(d_out) + f0 * (size_t)N * out_elem, p->num_cus, stream);
                 if (e != hipSuccess) break;
                 continue;
@@ -1013,9 +1013,11 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
         int M = 1;
         while (M < 2 * nfft - 1) M <<= 1;
         p->blu_m = M;
+        // work buffers of the five-pass form: 128 MiB each; the one-kernel form (M <= 16384) needs none and takes any batch whole
+        const bool one_kernel = sdrk::blu_fused_supports(M);
         size_t frames = ((size_t)128 << 20) / ((size_t)M * sizeof(float2));
         if (frames < 1) frames = 1;
-        if (frames > max_batch) frames = max_batch;
+        if (frames > max_batch || one_kernel) frames = max_batch;
         p->blu_frames = frames;
         int st2 = sdrk_plan_create(device, M, frames, SDRK_WINDOW_RECT, nullptr, 0.0f, 0, &p->blu_inner);
         if (st2 != SDRK_OK) { sdrk_plan_destroy(p); return st2; }
@@ -1029,8 +1031,8 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
         }
         PLAN_TRY(hipMalloc((void**)&p->d_blu_chirp, sizeof(float2) * nfft));
         PLAN_TRY(hipMemcpy(p->d_blu_chirp, c.data(), sizeof(float2) * nfft, hipMemcpyHostToDevice));
-        PLAN_TRY(hipMalloc((void**)&p->d_blu_a, frames * (size_t)M * sizeof(float2)));
-        PLAN_TRY(hipMalloc((void**)&p->d_blu_b, frames * (size_t)M * sizeof(float2)));
+        PLAN_TRY(hipMalloc((void**)&p->d_blu_a, (one_kernel ? 1 : frames) * (size_t)M * sizeof(float2)));   // (also carries b[] to its transform below)
+        if (!one_kernel) PLAN_TRY(hipMalloc((void**)&p->d_blu_b, frames * (size_t)M * sizeof(float2)));
         PLAN_TRY(hipMalloc((void**)&p->d_blu_bspec, (size_t)M * sizeof(float2)));
         PLAN_TRY(hipMemcpy(p->d_blu_a, b.data(), sizeof(float2) * M, hipMemcpyHostToDevice));
         st2 = plan_launch(p->blu_inner, p->d_blu_a, 1, (size_t)M, p->d_blu_bspec, sdrk::EPI_COMPLEX, p->stream);

@@ -41,7 +41,7 @@ def _kernels(tmp_path):
 
 def test_kernels_fit_their_register_budgets_and_do_not_spill(tmp_path):
     ks = _kernels(tmp_path)
-    assert len(ks) >= 140                                           # every template instantiation the plans can pick
+    assert len(ks) >= 130                                           # every template instantiation the plans can pick
     by = {k["name"]: k for k in ks}
     # the one known exception: Hann window + complex output of the N = 4096 kernel keeps two values in scratch (168 VGPRs + 12 B)
     # rather than give up its third workgroup per CU
