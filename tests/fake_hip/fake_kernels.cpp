@@ -66,7 +66,7 @@ hipError_t launch_fused64k(const LaunchArgs& a, void*, unsigned* d_ctrl) {
     return e;
 }
 bool blu_fused_supports(int) { return false; }
-hipError_t launch_blu_fused(const void*, size_t, size_t, int, int, const float*, const void*, const void*, const void*, void*, float,
+hipError_t launch_blu_fused(const void*, size_t, size_t, int, int, const float*, const void*, const void*, const void*, float,
                             int, int, void*, int, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_blu_pre(const void* d_iq, size_t stride, size_t nf, int N, int M, const float*, const void*, void* d_a, int, hipStream_t s) {
     fakehip::of(s).push([=] {
