@@ -1435,6 +1435,11 @@ def test_non_power_of_two_lengths_via_bluestein(pkg, n):
         assert int(np.argmax(pkg.spectrum_db(tone))) == (n // 2 + 2) % n
         rows = pkg.stft_db(np.tile(x[0], 3), n, max(1, n // 3))
         assert_db_parity(rows, cpu_ref.stft_db(np.tile(x[0], 3), n, max(1, n // 3)), what=f"stft n={n}")
+    if n in (100, 1000, 4095, 5000):
+        # the one-kernel form (M <= 16384) over many workgroup groups with a ragged last one, both epilogues
+        many = rand_c64(np.random.default_rng(n + 1), 1031 if n <= 1000 else 131, n, scale=40.0)
+        assert_db_parity(pkg.spectrum_db(many), cpu_ref.spectrum_db(many), what=f"n={n}, {len(many)} frames")
+        assert_complex_parity(pkg.fft_c64(many), cpu_ref.fft(many), what=f"fft n={n}, {len(many)} frames")
 
 
 def test_edge_cases_errors_and_special_values(pkg):
