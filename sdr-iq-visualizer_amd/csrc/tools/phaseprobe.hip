@@ -1,0 +1,80 @@
+// phaseprobe.hip — does separating reads and writes in TIME, chip-wide, buy HBM bandwidth for a 2:1 stream (32 KiB read, 16 KiB
+// written per frame, the flagship's traffic shape without its arithmetic)?  Every workgroup gates the ISSUE of its loads to a "read
+// window" and of its stores to a "write window" of a period P, told by the constant-rate real-time counter all CUs share
+// (s_memrealtime, 100 MHz) — no communication.  Variant 0: no gating (the software-pipelined copy).  Developer tool:
+//   hipcc --offload-arch=gfx950 -O3 -o phaseprobe phaseprobe.hip && ./phaseprobe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// wait until (now mod period) lies in [lo, hi)
+__device__ __forceinline__ void wait_window(unsigned period, unsigned lo, unsigned hi) {
+    for (int guard = 0; guard < 2000; ++guard) {            // bounded (~0.1 ms): a window always comes within one period
+        const unsigned t = (unsigned)(__builtin_amdgcn_s_memrealtime() % period);
+        if (t >= lo && t < hi) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+template <bool PHASED>
+__global__ __launch_bounds__(256, 3) void copy21(const float2* __restrict__ in, float* __restrict__ out, size_t n_frames,
+                                                 unsigned period, unsigned read_end) {
+    const int tid = threadIdx.x;
+    const size_t first = blockIdx.x, step = gridDim.x;
+    v2u nxt[16];
+    auto issue = [&](size_t fr) {
+        if (fr >= n_frames) fr = first;
+        __amdgpu_buffer_rsrc_t r = rsrc(in + fr * 4096, 4096 * 8);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, j * 2048, 2);
+    };
+    if (PHASED) wait_window(period, 0, read_end);
+    issue(first);
+    for (size_t f = first; f < n_frames; f += step) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __builtin_bit_cast(float, nxt[j].x) + __builtin_bit_cast(float, nxt[j].y);
+        if (PHASED) wait_window(period, 0, read_end);
+        issue(f + step);
+        if (PHASED) wait_window(period, read_end, period);
+        __amdgpu_buffer_rsrc_t w = rsrc(out + f * 4096, 4096 * 4);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), w, tid * 4, j * 1024, 2);
+    }
+}
+
+int main() {
+    const size_t frames = (size_t)1 << 19;                   // 16 GiB in, 8 GiB out
+    float2* in; float* out;
+    if (hipMalloc(&in, frames * 4096 * 8) != hipSuccess || hipMalloc(&out, frames * 4096 * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    (void)hipMemset(in, 0, frames * 4096 * 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto run = [&](int phased, unsigned period, unsigned read_end) {
+        auto launch = [&] {
+            if (phased) hipLaunchKernelGGL(copy21<true>, dim3(768), dim3(256), 0, 0, in, out, frames, period, read_end);
+            else hipLaunchKernelGGL(copy21<false>, dim3(768), dim3(256), 0, 0, in, out, frames, period, read_end);
+        };
+        for (int i = 0; i < 12; ++i) launch();               // > 50 ms of load: the shader clock has ramped
+        (void)hipDeviceSynchronize();
+        float best = 1e30f, sum = 0;
+        for (int r = 0; r < 5; ++r) {
+            (void)hipEventRecord(e0, 0); launch(); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); sum += ms; if (ms < best) best = ms;
+        }
+        const double gb = (double)frames * 4096 * 12 / 1e9;
+        if (phased) printf("phased  period %5.2f us  read window %4.0f %%   ", period / 100.0, 100.0 * read_end / period);
+        else printf("plain (software-pipelined, no gating)              ");
+        printf("%7.3f ms best %7.3f mean   %6.0f GB/s\n", best, sum / 5, gb / best * 1e3);
+        fflush(stdout);
+    };
+    run(0, 1, 1);
+    for (unsigned period : {300u, 450u, 600u, 800u, 1200u, 2000u})
+        for (unsigned pct : {50u, 60u, 67u})
+            run(1, period, period * pct / 100);
+    run(0, 1, 1);
+    return 0;
+}
