@@ -47,7 +47,45 @@ __global__ __launch_bounds__(256, 3) void copy21(const float2* __restrict__ in, 
     }
 }
 
-int main() {
+// the ungated copy with other access widths: LW = bytes per lane and load (8 / 16), SW = bytes per lane and store (4 / 8 / 16)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template <int LW, int SW>
+__global__ __launch_bounds__(256, 3) void copy21w(const float2* __restrict__ in, float* __restrict__ out, size_t n_frames) {
+    const int tid = threadIdx.x;
+    const size_t first = blockIdx.x, step = gridDim.x;
+    unsigned nxt[32];
+    auto issue = [&](size_t fr) {
+        if (fr >= n_frames) fr = first;
+        __amdgpu_buffer_rsrc_t r = rsrc(in + fr * 4096, 4096 * 8);
+        if (LW == 8) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { v2u t = __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, j * 2048, 2); nxt[2 * j] = t.x; nxt[2 * j + 1] = t.y; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, j * 4096, 2); nxt[4 * j] = t.x; nxt[4 * j + 1] = t.y; nxt[4 * j + 2] = t.z; nxt[4 * j + 3] = t.w; }
+        }
+    };
+    issue(first);
+    for (size_t f = first; f < n_frames; f += step) {
+        unsigned v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = nxt[2 * j] ^ nxt[2 * j + 1];
+        issue(f + step);
+        __amdgpu_buffer_rsrc_t w = rsrc(out + f * 4096, 4096 * 4);
+        if (SW == 4) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) __builtin_amdgcn_raw_buffer_store_b32(v[j], w, tid * 4, j * 1024, 2);
+        } else if (SW == 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b64(v2u{v[2 * j], v[2 * j + 1]}, w, tid * 8, j * 2048, 2);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(v4u{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]}, w, tid * 16, j * 4096, 2);
+        }
+    }
+}
+
+int main(int argc, char** argv) {
     const size_t frames = (size_t)1 << 19;                   // 16 GiB in, 8 GiB out
     float2* in; float* out;
     if (hipMalloc(&in, frames * 4096 * 8) != hipSuccess || hipMalloc(&out, frames * 4096 * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
@@ -71,6 +109,27 @@ int main() {
         printf("%7.3f ms best %7.3f mean   %6.0f GB/s\n", best, sum / 5, gb / best * 1e3);
         fflush(stdout);
     };
+    if (argc > 1) {      // access widths of the ungated copy
+        auto runw = [&](const char* name, void (*k)(const float2*, float*, size_t)) {
+            for (int i = 0; i < 12; ++i) hipLaunchKernelGGL(k, dim3(768), dim3(256), 0, 0, in, out, frames);
+            (void)hipDeviceSynchronize();
+            float best = 1e30f;
+            for (int r = 0; r < 7; ++r) {
+                (void)hipEventRecord(e0, 0); hipLaunchKernelGGL(k, dim3(768), dim3(256), 0, 0, in, out, frames); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+            }
+            printf("%-40s %7.3f ms   %6.0f GB/s\n", name, best, (double)frames * 4096 * 12 / 1e9 / best * 1e3); fflush(stdout);
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            runw("loads  8 B/lane, stores  4 B/lane", copy21w<8, 4>);
+            runw("loads 16 B/lane, stores  4 B/lane", copy21w<16, 4>);
+            runw("loads  8 B/lane, stores  8 B/lane", copy21w<8, 8>);
+            runw("loads 16 B/lane, stores  8 B/lane", copy21w<16, 8>);
+            runw("loads 16 B/lane, stores 16 B/lane", copy21w<16, 16>);
+            runw("loads  8 B/lane, stores 16 B/lane", copy21w<8, 16>);
+        }
+        return 0;
+    }
     run(0, 1, 1);
     for (unsigned period : {300u, 450u, 600u, 800u, 1200u, 2000u})
         for (unsigned pct : {50u, 60u, 67u})
