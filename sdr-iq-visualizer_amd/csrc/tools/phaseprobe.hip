@@ -85,6 +85,31 @@ __global__ __launch_bounds__(256, 3) void copy21w(const float2* __restrict__ in,
     }
 }
 
+// the same traffic with ONE WAVE per frame (64 points per lane, prefetched one frame ahead: 32 KiB in flight per wave), WPC waves
+// per CU: the memory side of a wave-per-frame transform kernel
+template <int DUMMY>
+__global__ __launch_bounds__(256, 1) void copy21_wave(const float2* __restrict__ in, float* __restrict__ out, size_t n_frames) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t first = (size_t)blockIdx.x * 4 + wave, step = (size_t)gridDim.x * 4;
+    v2u nxt[64];
+    auto issue = [&](size_t fr) {
+        if (fr >= n_frames) fr = first;
+        __amdgpu_buffer_rsrc_t r = rsrc(in + fr * 4096, 4096 * 8);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) nxt[j] = __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8, j * 512, 2);
+    };
+    issue(first);
+    for (size_t f = first; f < n_frames; f += step) {
+        float v[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) v[j] = __builtin_bit_cast(float, nxt[j].x) + __builtin_bit_cast(float, nxt[j].y);
+        issue(f + step);
+        __amdgpu_buffer_rsrc_t w = rsrc(out + f * 4096, 4096 * 4);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), w, lane * 4, j * 256, 2);
+    }
+}
+
 int main(int argc, char** argv) {
     const size_t frames = (size_t)1 << 19;                   // 16 GiB in, 8 GiB out
     float2* in; float* out;
@@ -120,6 +145,24 @@ int main(int argc, char** argv) {
             }
             printf("%-40s %7.3f ms   %6.0f GB/s\n", name, best, (double)frames * 4096 * 12 / 1e9 / best * 1e3); fflush(stdout);
         };
+        if (argv[1][0] == 'v') {     // "vave": one wave per frame against the workgroup-per-frame copy, alternating
+            auto runv = [&](const char* name, int grid) {
+                for (int i = 0; i < 12; ++i) hipLaunchKernelGGL(copy21_wave<0>, dim3(grid), dim3(256), 0, 0, in, out, frames);
+                (void)hipDeviceSynchronize();
+                float best = 1e30f;
+                for (int r = 0; r < 7; ++r) {
+                    (void)hipEventRecord(e0, 0); hipLaunchKernelGGL(copy21_wave<0>, dim3(grid), dim3(256), 0, 0, in, out, frames); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+                }
+                printf("%-40s %7.3f ms   %6.0f GB/s\n", name, best, (double)frames * 4096 * 12 / 1e9 / best * 1e3); fflush(stdout);
+            };
+            for (int rep = 0; rep < 2; ++rep) {
+                runw("workgroup per frame, 3 per CU (ships)", copy21w<8, 4>);
+                runv("wave per frame, 4 waves per CU", 256);
+                runv("wave per frame, 4 waves per CU, grid x2", 512);
+            }
+            return 0;
+        }
         for (int rep = 0; rep < 2; ++rep) {
             runw("loads  8 B/lane, stores  4 B/lane", copy21w<8, 4>);
             runw("loads 16 B/lane, stores  4 B/lane", copy21w<16, 4>);
