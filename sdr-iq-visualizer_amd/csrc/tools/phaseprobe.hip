@@ -85,6 +85,37 @@ __global__ __launch_bounds__(256, 3) void copy21w(const float2* __restrict__ in,
     }
 }
 
+// the workgroup-per-frame copy with DEPTH frames prefetched (registers) and PER_CU workgroups per CU
+template <int DEPTH, int PER_CU>
+__global__ __launch_bounds__(256, PER_CU) void copy21d(const float2* __restrict__ in, float* __restrict__ out, size_t n_frames) {
+    const int tid = threadIdx.x;
+    const size_t first = blockIdx.x, step = gridDim.x;
+    v2u q[DEPTH][16];
+    auto issue = [&](v2u (&x)[16], size_t fr) {
+        if (fr >= n_frames) fr = first;
+        __amdgpu_buffer_rsrc_t r = rsrc(in + fr * 4096, 4096 * 8);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, j * 2048, 2);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(q[d], first + d * step);
+    for (size_t f = first; f < n_frames; f += step * DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const size_t fd = f + d * step;
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = __builtin_bit_cast(float, q[d][j].x) + __builtin_bit_cast(float, q[d][j].y);
+            issue(q[d], fd + step * DEPTH);
+            if (fd < n_frames) {
+                __amdgpu_buffer_rsrc_t w = rsrc(out + fd * 4096, 4096 * 4);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), w, tid * 4, j * 1024, 2);
+            }
+        }
+    }
+}
+
 // the same traffic with ONE WAVE per frame (64 points per lane, prefetched one frame ahead: 32 KiB in flight per wave), WPC waves
 // per CU: the memory side of a wave-per-frame transform kernel
 template <int DUMMY>
@@ -156,6 +187,25 @@ int main(int argc, char** argv) {
                 }
                 printf("%-40s %7.3f ms   %6.0f GB/s\n", name, best, (double)frames * 4096 * 12 / 1e9 / best * 1e3); fflush(stdout);
             };
+            auto rund = [&](const char* name, void (*k)(const float2*, float*, size_t), int grid) {
+                for (int i = 0; i < 12; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, 0, in, out, frames);
+                (void)hipDeviceSynchronize();
+                float best = 1e30f;
+                for (int r = 0; r < 7; ++r) {
+                    (void)hipEventRecord(e0, 0); hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, 0, in, out, frames); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+                }
+                printf("%-40s %7.3f ms   %6.0f GB/s\n", name, best, (double)frames * 4096 * 12 / 1e9 / best * 1e3); fflush(stdout);
+            };
+            for (int rep = 0; rep < 2; ++rep) {
+                rund("workgroup per frame: 3 per CU, depth 1", copy21d<1, 3>, 768);
+                rund("workgroup per frame: 2 per CU, depth 1", copy21d<1, 2>, 512);
+                rund("workgroup per frame: 2 per CU, depth 2", copy21d<2, 2>, 512);
+                rund("workgroup per frame: 3 per CU, depth 2", copy21d<2, 3>, 768);
+                rund("workgroup per frame: 1 per CU, depth 4", copy21d<4, 1>, 256);
+                rund("workgroup per frame: 1 per CU, depth 2", copy21d<2, 1>, 256);
+                rund("workgroup per frame: 4 per CU, depth 1", copy21d<1, 4>, 1024);
+            }
             for (int rep = 0; rep < 2; ++rep) {
                 runw("workgroup per frame, 3 per CU (ships)", copy21w<8, 4>);
                 runv("wave per frame, 4 waves per CU", 256);
