@@ -38,7 +38,7 @@
 
 namespace sdrk {
 
-// (Tried and dropped, A/B on the same buffers: twiddles by product tree instead of LDS tables (neutral), a sqrt-free
+// (Tried and dropped, A/B on the same buffers: two frames prefetched (2 % slower, again in round 5 at 140 VGPRs), a sqrt-free
 // log epilogue (1.5 % slower), and sending the row through LDS once more so that it leaves as four 16-byte stores
 // per thread instead of sixteen 4-byte ones (1.0-1.5 % slower: two more barriers per frame cost more than the
 // narrower stores do); issuing the prefetch through inline asm with an exact `s_waitcnt vmcnt(16)` in front of its first
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
     float eps, int shift) {
     __shared__ float2 lds[F4K_XCH_ELEMS + F4K_TW_ELEMS + ((HAS_WINDOW && !F4K_WINREG) ? F4K_N / 2 : 0)];
     float2* __restrict__ tw256 = lds + F4K_XCH_ELEMS;  // [k][n] = W256^(n k)
-    float2* __restrict__ tw4k = tw256 + 256;           // [k][n] = W4096^(n k), n,k < 16
-    float* __restrict__ lds_win = reinterpret_cast<float*>(tw4k + 256);
+    float2* __restrict__ tw1 = tw256 + 256;            // W4096^tid
+    float* __restrict__ lds_win = reinterpret_cast<float*>(tw1 + 256);
 
     const int tid = threadIdx.x;
     F4kAddr A = f4k_addr(tid);
-    f4k_init_tables(tw256, tw4k, tw4096, tid, A);
+    f4k_init_tables(tw256, tw1, tw4096, tid, A);
 #if F4K_WINREG
     float win[16];
     if (HAS_WINDOW) {
@@ -102,9 +102,9 @@ __global__ __launch_bounds__(F4K_THREADS, F4K_WAVES) void fft4096_kernel(
 #pragma unroll
             for (int j = 0; j < 16; ++j) win[j] = lds_win[tid + 256 * j];
 #endif
-            f4k_transform<true>(v, lds, tw256, tw4k, A, tid, win);
+            f4k_transform<true>(v, lds, tw256, tw1, A, tid, win);
         } else {
-            f4k_transform(v, lds, tw256, tw4k, A, tid);
+            f4k_transform(v, lds, tw256, tw1, A, tid);
         }
         // ---- epilogue + store: bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor) ----
         __amdgpu_buffer_rsrc_t w = frame_rsrc(

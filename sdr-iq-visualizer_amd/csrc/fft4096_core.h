@@ -13,7 +13,7 @@ constexpr int F4K_THREADS = 256;
 #define F4K_WAVES 3  // waves per SIMD = workgroups per CU (<=168 VGPRs)
 #endif
 constexpr int F4K_XCH_ELEMS = 4112;  // exchange buffer (max index 4110), 32,896 B
-constexpr int F4K_TW_ELEMS = 512;    // W256^(n k) and W4096^(n k) as [k][n], 2 KiB each
+constexpr int F4K_TW_ELEMS = 512;    // W256^(n k) as [k][n] and W4096^tid, 2 KiB each
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
@@ -43,14 +43,16 @@ __device__ __forceinline__ F4kAddr f4k_addr(int tid) {
     return a;
 }
 
-// Fill the two 2 KiB twiddle tables [k][n] from the global W4096^m table.
+// Fill the two 2 KiB tables from the global W4096^m table: W256^(n k) as [k][n] (pass 2) and each thread's W4096^tid, the base
+// of its pass-1 twiddles (they are its powers: pow_tree, as in fft_lds_core.h — one LDS read per frame and thread where two
+// table reads and a product per twiddle were 30; parity unchanged, 162 -> 126 VGPRs in the flagship, DESIGN_APPENDIX.md A.13).
 // Caller must __syncthreads() before the first f4k_transform().
-__device__ __forceinline__ void f4k_init_tables(float2* __restrict__ tw256, float2* __restrict__ tw4k,
+__device__ __forceinline__ void f4k_init_tables(float2* __restrict__ tw256, float2* __restrict__ tw1,
                                                 const float2* __restrict__ tw4096, int tid, F4kAddr& A) {
     (void)A;
     const int lo = tid & 15, hi = tid >> 4;
     tw256[tid] = tw4096[(16 * lo * hi) & (F4K_N - 1)];  // [k=hi][n=lo] = W256^(lo hi)
-    tw4k[tid] = tw4096[lo * hi];                         // [k=hi][n=lo] = W4096^(lo hi)
+    tw1[tid] = tw4096[tid];                              // W4096^tid
 }
 
 // w[k] = w1^k for k = 1..15 with multiplication depth <= 4 (w2=w1^2, w4=w2^2, w8=w4^2).
@@ -79,14 +81,16 @@ __device__ __forceinline__ void pow_tree(cf w1, cf (&w)[16]) {
 template <bool WIN = false>
 __device__ __forceinline__ void f4k_transform(cf (&v)[16], float2* __restrict__ lds,
                                               const float2* __restrict__ tw256,
-                                              const float2* __restrict__ tw4k, const F4kAddr& A,
+                                              const float2* __restrict__ tw1, const F4kAddr& A,
                                               int tid, const float* __restrict__ win = nullptr) {
-    // ---- pass 1: DFT-16 over n2, times W4096^(r k0) = tw4k[k0][n0] * tw256[k0][n1] ----
+    // ---- pass 1: DFT-16 over n2, times W4096^(r k0) = (W4096^r)^k0, r = tid ----
     radix16<WIN>(v, win);
+    {
+        const float2 t1 = tw1[tid];
+        cf w[16];
+        pow_tree(cf{t1.x, t1.y}, w);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        float2 wa = tw4k[16 * k + A.lo], wb = tw256[16 * k + A.hi];
-        v[rev16(k)] = cmul(v[rev16(k)], cmul(cf{wa.x, wa.y}, cf{wb.x, wb.y}));
+        for (int k = 1; k < 16; ++k) v[rev16(k)] = cmul(v[rev16(k)], w[k]);
     }
     __syncthreads();  // previous transform's pass-3 reads are done
 #pragma unroll

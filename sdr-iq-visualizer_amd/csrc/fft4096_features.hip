@@ -42,14 +42,14 @@ __global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kern
     static_assert((F4K_N * sizeof(float)) % alignof(RowFeatShared) == 0 && alignof(RowFeatShared) <= 16,
                   "RowFeatShared sits behind the row at an offset that keeps its alignment");
     float2* __restrict__ tw256 = lds + F4K_XCH_ELEMS;
-    float2* __restrict__ tw4k = tw256 + 256;
+    float2* __restrict__ tw1 = tw256 + 256;
     float* __restrict__ row = reinterpret_cast<float*>(lds);                                  // 4096 float32
     RowFeatShared& sh = *reinterpret_cast<RowFeatShared*>(reinterpret_cast<char*>(lds) + F4K_N * sizeof(float));
 
     {
         const int tid = threadIdx.x;
         F4kAddr A = f4k_addr(tid);
-        f4k_init_tables(tw256, tw4k, tw4096, tid, A);
+        f4k_init_tables(tw256, tw1, tw4096, tid, A);
     }
     __syncthreads();
 
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(F4K_THREADS, F4KF_WAVES) void fft4096_features_kern
                 win[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwin, tid * 4, j * 1024, 0));
         }
         SDRK_PHASE("transform");
-        if (HAS_WINDOW) f4k_transform<true>(v, lds, tw256, tw4k, A, tid, win);
-        else f4k_transform(v, lds, tw256, tw4k, A, tid);
+        if (HAS_WINDOW) f4k_transform<true>(v, lds, tw256, tw1, A, tid, win);
+        else f4k_transform(v, lds, tw256, tw1, A, tid);
         __syncthreads();   // every thread is through its last exchange read: the buffer becomes the row
         SDRK_PHASE("logpsd_row");
         // bin k = tid + 256 k2 -> index tid + 256 (k2 ^ xor)

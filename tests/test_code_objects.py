@@ -43,11 +43,9 @@ def test_kernels_fit_their_register_budgets_and_do_not_spill(tmp_path):
     ks = _kernels(tmp_path)
     assert len(ks) >= 130                                           # every template instantiation the plans can pick
     by = {k["name"]: k for k in ks}
-    # the one known exception: Hann window + complex output of the N = 4096 kernel keeps two values in scratch (168 VGPRs + 12 B)
-    # rather than give up its third workgroup per CU
     spilling = {n: (k["private_segment_fixed_size"], k["vgpr_spill_count"]) for n, k in by.items()
                 if k["private_segment_fixed_size"] or k["vgpr_spill_count"]}   # (SGPRs spilled into VGPR lanes cost no memory)
-    assert all("fft4096_kernelILb1ELi1E" in n and s[0] <= 16 for n, s in spilling.items()), spilling
+    assert not spilling, spilling
 
     def one(fragment):
         hits = [k for n, k in by.items() if fragment in n]
@@ -56,7 +54,7 @@ def test_kernels_fit_their_register_budgets_and_do_not_spill(tmp_path):
 
     # flagship: three workgroups of 256 threads per CU = three waves per SIMD -> at most 512 / 3 = 170 registers, 160 KiB / 3 of LDS
     for k in one("fft4096_kernelILb"):
-        assert k["vgpr_count"] <= 168 and k["group_segment_fixed_size"] <= 160 * 1024 // 3
+        assert k["vgpr_count"] <= 128 and k["group_segment_fixed_size"] <= 160 * 1024 // 3   # (126 since the pass-1 twiddles are powers of one base)
     # the feature kernel: four per CU -> 128 registers, 40 KiB
     for k in one("fft4096_features_kernel"):
         assert k["vgpr_count"] <= 128 and k["group_segment_fixed_size"] <= 40 * 1024
@@ -94,5 +92,5 @@ def test_transform_kernels_use_packed_complex_arithmetic_and_the_feature_kernel_
                     counts[cur][0] += 1
     flag = next(v for n, v in counts.items() if "fft4096_kernelILb1ELi0E" in n)
     feat = next(v for n, v in counts.items() if "fft4096_features_kernelILb1E" in n)
-    assert flag[0] >= 300 and flag[1] <= 520, flag                  # 329 packed of 479 VALU instructions (scalar form: 800)
+    assert flag[0] >= 300 and flag[1] <= 520, flag                  # 327 packed of 473 VALU instructions (scalar form: ~800)
     assert feat[0] == 0, feat
