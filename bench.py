@@ -64,10 +64,11 @@ def parse_args():
                     help="budget of EACH of the four CPU legs beside configs 3 and 5 (one core / all cores; 0 disables)")
     ap.add_argument("--parity-frames", type=int, default=1024,
                     help="random frames of the timed output checked against the oracle (SURVEY.md §8d: >= 1024)")
-    ap.add_argument("--placement-candidates", type=int, default=10,
+    ap.add_argument("--placement-candidates", type=int, default=6,
                     help="output-buffer placements probed for the resident pair (1 = plain allocation).  The level a pair runs at is a "
                          "lottery (DESIGN.md 4.1): of the 144 pairings probed in rounds 3-5, 3 % (one box) to 22 % (another) were on the "
-                         "fast level; ten tickets instead of six cost 0.2 s and 64 GiB more while probing")
+                         "fast level.  Six since round 6 (round 5 drew ten: +15 s of wall time, and the driver's series 0.714 / 0.693 / "
+                         "0.706 could not see a gain — the box-to-box spread is larger)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip configs 3/5, the numpy boundary and the feature-reduction legs")
     return ap.parse_args()

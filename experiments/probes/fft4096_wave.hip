@@ -9,7 +9,7 @@
 // four such waves per CU (one per SIMD).  A wave reads its frame as 64 consecutive 512-byte pieces and writes its row as 64
 // consecutive 256-byte pieces: the no-arithmetic copy of that shape streams 5 % faster than the workgroup-per-frame one
 // (tools/phaseprobe.hip vave).  Same decomposition as fft_lds_core.h for N = 4096 = 16 x 16 x 16 (twiddles by power tree).
-#include "../fft_lds_core.h"
+#include "../../sdr-iq-visualizer_amd/csrc/fft_lds_core.h"
 
 namespace sdrk {
 

@@ -4,8 +4,8 @@
 // with the same bytes (the practical ceiling for this traffic shape).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DF4K_...] kbench.hip -o kbench_<tag>
 //   ./kbench_<tag> [log2_frames=20] [reps=20] [window=1]
-#include "../fft4096.hip"
-#include "../aux_kernels.hip"
+#include "../../sdr-iq-visualizer_amd/csrc/fft4096.hip"
+#include "../../sdr-iq-visualizer_amd/csrc/aux_kernels.hip"
 
 #include <algorithm>
 #include <cstdio>

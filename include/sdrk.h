@@ -80,7 +80,7 @@ int sdrk_dev_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
  * interfere least.  On MI355X the achieved rate of a kernel that streams one buffer in and another out (the
  * spectrum path: 8 B in, 4 B out per sample) has two or three discrete levels ~6 % apart that depend on WHICH
  * two allocations are paired — read-only and (with rare exceptions) write-only rates do not depend on the buffer, and the level is
- * stable for the life of the pair (csrc/tools/placeprobe.hip).  This call allocates the input,
+ * stable for the life of the pair (experiments/probes/placeprobe.hip).  This call allocates the input,
  * then up to `candidates` outputs (earlier ones stay allocated meanwhile, so each lands elsewhere), times a
  * probe over each pairing (after a warm-up by time; candidate 0 is timed again at the end and counts with the better of
  * its two timings: sdrk_placement_report) and keeps the fastest.  The probe is `plan`'s own transform over the pair (packed

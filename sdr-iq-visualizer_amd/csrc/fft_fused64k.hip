@@ -43,8 +43,12 @@ constexpr int FU_THREADS = 256;
 constexpr int FU_N = 65536;
 constexpr int FU_A = 256;                  // = M
 #ifndef FU_RING_SLOTS_N
-#define FU_RING_SLOTS_N 2
+#define FU_RING_SLOTS_N 1
 #endif
+#if !defined(SDRK_FUSED_EXPERIMENT) || !defined(FU_KNOCK)
+#undef FU_KNOCK
+#define FU_KNOCK 0   // experiment builds only (timing, wrong results): 1 every workgroup a col workgroup, 2 every one a row workgroup,
+#endif               // 3 no ring traffic, 4 no transforms
 constexpr int FU_SLEEP = 4;                // x 64 clocks between two polls of a wave
 constexpr int FU_RING_SLOTS = FU_RING_SLOTS_N;   // D; x 512 KiB per set, three sets per XCD
 constexpr int FU_MAX_XCD = 16;
@@ -63,6 +67,15 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
 }
 __device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A set's own flags (col_done / row_done) are stored WITHOUT scope bits.  An agent-scope store is `global_store_dword ... sc1`,
+// which writes through and DROPS the line from the L2 (MI355X_MICROARCH.md, "stores of each flavour"): every poll then missed
+// the L2 and went to the fabric — rounds 1-5 paid 1.2 ms per 4096 frames for that, more than the transform itself (2.41 -> 1.20 ms,
+// profiles/r06/fused64k_policy.md).  A plain store stays in the L2 that both sides were verified, by XCC id, to share; the
+// pollers' sc1 loads bypass their CU's L1 and are served by that L2.  Ordering: the storing wave has waited `vmcnt(0)` for its
+// ring accesses before this store is issued, and the asm's memory clobber keeps the compiler from moving anything across it.
+__device__ __forceinline__ void st_flag(unsigned* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
 // Every lane polls one of the 64 words until all of them are >= want.  Wave-uniform result; false = timeout or
@@ -100,7 +113,10 @@ __device__ __forceinline__ bool wg_wait_all(const unsigned* words, unsigned want
     return ok;
 }
 
-template <bool HAS_WINDOW, int EPILOGUE, int SH>
+// IN_AUX / OUT_AUX: cache-policy bits of the streamed input loads and row stores (buffer aux: 1 = sc0, 2 = nt, 16 = sc1); NOWAIT
+// compiles the hand-over's waits out (wrong results; for timing the traffic alone).  The product instantiates the defaults only;
+// experiments/fused64k_policy (round 6) instantiates the sweep behind -DSDRK_FUSED_EXPERIMENT.
+template <bool HAS_WINDOW, int EPILOGUE, int SH, int IN_AUX = 2, int OUT_AUX = 2, bool NOWAIT = false>
 __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
     const float2* __restrict__ iq, size_t frame_stride, void* __restrict__ out_raw, unsigned n_frames,
     const float* __restrict__ window, const float2* __restrict__ tw256, const float2* __restrict__ t1T,
@@ -109,7 +125,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
     using C = LdsCfg<8>;
     constexpr int M = FU_A, T = C::T, D = FU_RING_SLOTS;   // T = 16 threads per 256-point transform
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];   // 16 x SLOT (exchange) / [256][17] transpose tile
-    __shared__ unsigned sh_role[2];
+    __shared__ unsigned sh_role[3];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -142,23 +158,31 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
         }
         sh_role[0] = g;
         sh_role[1] = member;
+        sh_role[2] = xcc;
     }
     __syncthreads();
     const unsigned g = sh_role[0], member = sh_role[1];
     if (g >= n_sets) return;                         // a surplus workgroup, or the set never got its number
     unsigned* __restrict__ col_done = ctrl + 256 + (size_t)g * 128;
     unsigned* __restrict__ row_done = col_done + 64;
+#if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_ALIAS_RING)
+    // timing only (with NOWAIT): every set of an XCD uses the SAME ring — what full occupancy over one L2-resident ring would cost
+    float2* __restrict__ my_ring = ring + (size_t)sh_role[2] * D * FU_N;
+#else
     float2* __restrict__ my_ring = ring + (size_t)g * D * FU_N;
+#endif
     const size_t run = ((size_t)n_frames + n_sets - 1) / n_sets;
     const size_t f_begin = g * run, f_end = f_begin + run < n_frames ? f_begin + run : n_frames;
     if (f_begin >= f_end) return;
 
-    if (member < 16) {
-        // ---------------- col workgroup of tile position `member` ----------------
+    const unsigned pos = member & 15;
+    const bool is_col = FU_KNOCK == 1 ? true : FU_KNOCK == 2 ? false : member < 16;
+    if (is_col) {
+        // ---------------- col workgroup of tile position `pos` ----------------
         const int fr = tid & 15, tau = tid >> 4;
         LdsTw<8> tw;
         lds_tw_init<8>(tw, tw256, tau);
-        const int m = (int)member * 16 + fr;
+        const int m = (int)pos * 16 + fr;
         float wreg[16];
         if (HAS_WINDOW) {
 #pragma unroll
@@ -183,7 +207,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
             const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + (live ? f : f_begin) * frame_stride, live ? (unsigned)(FU_N * 8) : 0u);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (q >= q0) x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, 2));
+                if (q >= q0) x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, IN_AUX));
         };
         const int so = scratch_index(tau, m, M);
         v2f xa[16], xb[16];
@@ -194,44 +218,47 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
             cf v[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = HAS_WINDOW ? cf{xa[q].x, xa[q].y} * wreg[q] : cf{xa[q].x, xa[q].y};
-            lds_fft_core<8, 16>(v, lds_all, fr, tau, tw);
+            if (FU_KNOCK != 4) lds_fft_core<8, 16>(v, lds_all, fr, tau, tw);
             // the ring slot must have been read by every row workgroup (frame s - D)
-            if (s >= (unsigned)D && !wg_wait_all(row_done, s - D + 1, ctrl, 1, sh_role)) return;
+            if (!NOWAIT && s >= (unsigned)D && !wg_wait_all(row_done, s - D + 1, ctrl, 1, sh_role)) return;
             const __amdgpu_buffer_rsrc_t ro = frame_rsrc(my_ring + (size_t)(s % D) * FU_N, (unsigned)(FU_N * 8));
+            if (FU_KNOCK != 3 || eps < -1e30f) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf z = cmul(v[rev16(q)], bw[q]);
                 const v2f sv = {z.x, z.y};
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, scratch_index(T * q, 0, M) * 8, 0);
             }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's ring stores are in the L2
-            if ((tid & 63) == 0) st_agent(col_done + member * 4 + wave, s + 1);
+            if ((tid & 63) == 0) st_flag(col_done + pos * 4 + wave, s + 1);
 #pragma unroll
             for (int q = 0; q < 16; ++q) xa[q] = q < 16 - SH ? xa[q + SH] : xb[q];
         }
     } else {
-        // ---------------- row workgroup of row tile `member - 16` ----------------
+        // ---------------- row workgroup of row tile `pos` ----------------
         const int fr = tid / T, rt = tid - fr * T;
         float2* __restrict__ lds = lds_all + (size_t)fr * C::SLOT;
         LdsTw<8> tw;
         lds_tw_init<8>(tw, tw256, rt);
-        const int k3_0 = (int)(member - 16) * 16;
+        const int k3_0 = (int)pos * 16;
         const int xor_q = shift ? 8 : 0;
         const int e0 = scratch_index(fr, rt, M);
         for (size_t f = f_begin; f < f_end; ++f) {
             const unsigned s = (unsigned)(f - f_begin);
-            if (!wg_wait_all(col_done, s + 1, ctrl, 2, sh_role)) return;
+            if (!NOWAIT && !wg_wait_all(col_done, s + 1, ctrl, 2, sh_role)) return;
             const __amdgpu_buffer_rsrc_t ri = frame_rsrc(my_ring + (size_t)(s % D) * FU_N + (size_t)k3_0 * M, (unsigned)(16 * M * 8));
             cf v[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
+                if (FU_KNOCK == 3 && !(eps < -1e30f)) { v[c] = cf{(float)s * 1e-3f + (float)tid, (float)c}; continue; }
                 // sc1: served by this XCD's L2, never by this CU's (possibly stale) L1
                 const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, c * T, M) * 8, 16));
                 v[c] = cf{x.x, x.y};
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's ring loads have returned
-            if ((tid & 63) == 0) st_agent(row_done + (member - 16) * 4 + wave, s + 1);
-            lds_fft_core<8, 1>(v, lds, 0, rt, tw);
+            if ((tid & 63) == 0) st_flag(row_done + pos * 4 + wave, s + 1);
+            if (FU_KNOCK != 4) lds_fft_core<8, 1>(v, lds, 0, rt, tw);
             __syncthreads();  // all rows are through their last LDS reads: the buffer becomes the transpose tile
             if (EPILOGUE == EPI_LOGPSD) {
                 float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][17]
@@ -248,7 +275,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
                 for (int i = 0; i < 16; ++i) {
                     const float val = tile[(km0 + T * i) * 17 + r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, (km0 * FU_A + r) * 4,
-                                                          i * T * FU_A * 4, 2);
+                                                          i * T * FU_A * 4, OUT_AUX);
                 }
             } else {
                 float2* __restrict__ tile = lds_all;  // [km][17]
@@ -273,8 +300,20 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
 
 size_t fused64k_ring_bytes() { return (size_t)FU_MAX_SETS * FU_RING_SLOTS * FU_N * sizeof(float2); }
 size_t fused64k_ctrl_words() { return FU_CTRL_WORDS; }
+#ifdef SDRK_FUSED_EXPERIMENT
+// Round-6 policy sweep (experiments/fused64k_policy/): workgroups per CU, the cache-policy bits of the streamed accesses and the
+// timing-only NOWAIT build are picked per process from the environment.  Never defined in the product build.
+static int fu_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+#endif
 unsigned fused64k_sets(int num_cus) {
-    const unsigned n = (unsigned)num_cus * 3 / 32;       // three workgroups per CU are resident
+    unsigned wg_per_cu = 3;                              // three workgroups per CU are resident
+#ifdef SDRK_FUSED_EXPERIMENT
+    wg_per_cu = (unsigned)fu_env("SDRK_FU_WG_PER_CU", 3);
+#endif
+    const unsigned n = (unsigned)num_cus * wg_per_cu / 32;
     return n > (unsigned)FU_MAX_SETS ? (unsigned)FU_MAX_SETS : n;
 }
 
@@ -302,6 +341,37 @@ hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl) 
                        a.frame_stride, a.d_out, (unsigned)a.n_frames, a.d_window, twA, t1T, t2, ring, d_ctrl,     \
                        n_sets, sets_per_xcd, a.eps, a.shift)
 #define SDRK_FU2(W, E) do { if (sh == 8) SDRK_FU(W, E, 8); else SDRK_FU(W, E, 16); } while (0)
+#ifdef SDRK_FUSED_EXPERIMENT
+    if (a.epilogue == EPI_LOGPSD && a.d_window) {
+        const int pin = fu_env("SDRK_FU_IN_AUX", 2), pout = fu_env("SDRK_FU_OUT_AUX", 2), nowait = fu_env("SDRK_FU_NOWAIT", 0);
+        bool hit = false;
+#define SDRK_FUX(I, O, NW)                                                                                      \
+        if (!hit && pin == I && pout == O && nowait == (NW ? 1 : 0)) {                                            \
+            hit = true;                                                                                           \
+            if (sh == 8)                                                                                          \
+                hipLaunchKernelGGL((fused64k_kernel<true, EPI_LOGPSD, 8, I, O, NW>), dim3(grid), dim3(FU_THREADS), \
+                                   lds_bytes, a.stream, iq, a.frame_stride, a.d_out, (unsigned)a.n_frames,          \
+                                   a.d_window, twA, t1T, t2, ring, d_ctrl, n_sets, sets_per_xcd, a.eps, a.shift);   \
+            else                                                                                                  \
+                hipLaunchKernelGGL((fused64k_kernel<true, EPI_LOGPSD, 16, I, O, NW>), dim3(grid), dim3(FU_THREADS), \
+                                   lds_bytes, a.stream, iq, a.frame_stride, a.d_out, (unsigned)a.n_frames,          \
+                                   a.d_window, twA, t1T, t2, ring, d_ctrl, n_sets, sets_per_xcd, a.eps, a.shift);   \
+        }
+#define SDRK_FUX_OUT(I, NW) SDRK_FUX(I, 2, NW) SDRK_FUX(I, 0, NW) SDRK_FUX(I, 16, NW) SDRK_FUX(I, 17, NW) SDRK_FUX(I, 19, NW)
+#ifdef FU_FEW   // knock-out builds: two policies are enough
+#define SDRK_FUX_IN(NW) SDRK_FUX(2, 2, NW) SDRK_FUX(2, 17, NW)
+#else
+#define SDRK_FUX_IN(NW) SDRK_FUX_OUT(2, NW) SDRK_FUX_OUT(0, NW) SDRK_FUX_OUT(18, NW) SDRK_FUX_OUT(19, NW)
+#endif
+        SDRK_FUX_IN(false)
+        SDRK_FUX_IN(true)
+#undef SDRK_FUX_IN
+#undef SDRK_FUX_OUT
+#undef SDRK_FUX
+        if (!hit) return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+#endif
     if (a.epilogue == EPI_LOGPSD) {
         if (a.d_window) SDRK_FU2(true, EPI_LOGPSD); else SDRK_FU2(false, EPI_LOGPSD);
     } else {

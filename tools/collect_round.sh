@@ -28,7 +28,7 @@ case $PART in *B*) ;; *) exit 0;; esac
 if [ "$LIGHT" != 1 ]; then
 echo "== placement probes"
 mkdir -p sdr-iq-visualizer_amd/build_tools
-for t in placeprobe queueprobe; do hipcc --offload-arch=gfx950 -O3 -o sdr-iq-visualizer_amd/build_tools/$t sdr-iq-visualizer_amd/csrc/tools/$t.hip 2>/dev/null; done
+for t in placeprobe queueprobe; do hipcc --offload-arch=gfx950 -O3 -o sdr-iq-visualizer_amd/build_tools/$t experiments/probes/$t.hip 2>/dev/null; done
 { for i in 1 2 3; do ./sdr-iq-visualizer_amd/build_tools/placeprobe 20 3; done; for i in 1 2 3 4; do ./sdr-iq-visualizer_amd/build_tools/queueprobe 19 4; done; } > "$OUT/placeprobe.log" 2>&1
 fi
 NP=12; NQ=6; [ "$LIGHT" = 1 ] && { NP=6; NQ=3; }
@@ -37,7 +37,7 @@ summ() { python3 -c "
 import json,sys
 l=json.loads(sys.stdin.read()); t=l['telemetry']
 print('%.4f  %.4f  %.4f  %.4f  %7.1f  %.4f  sclk_after %s  probe_ms %s chosen %d' % (l['launch_ms']['median'], l['launch_ms']['min'], l['launch_ms']['max'], l['roofline']['frac'], l['roofline']['measured_copy_GBps'], l['roofline']['frac_of_measured_copy'], t['after']['sclk_mhz'], l['placement']['probe_ms'], l['placement']['chosen']))"; }
-{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   ($NP processes; placement: 10 candidates)";
+{ echo "# python bench.py --no-secondary --cpu-seconds 0 --parity-frames 0   ($NP processes; placement: 6 candidates)";
   echo "# launch_ms median  min  max  frac_of_8TB/s  copy_GB/s  kernel/copy";
   for i in $(seq $NP); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 2>/dev/null | tail -1 | summ; done; } > "$OUT/placement_runs.txt"
 { echo "# the same with --placement-candidates 1 (plain alloc(in); alloc(out)), $NQ processes";
@@ -73,7 +73,7 @@ rm -rf "$OUT"/trace_*/
 cat "$OUT/overlap_trace_summary.txt"
 echo "== host link: pageable / registered / pinned copies of 1 GiB in + 0.5 GiB out"
 mkdir -p sdr-iq-visualizer_amd/build_tools
-hipcc --offload-arch=gfx950 -O3 -o sdr-iq-visualizer_amd/build_tools/pcie_probe sdr-iq-visualizer_amd/csrc/tools/pcie_probe.hip 2>/dev/null && ./sdr-iq-visualizer_amd/build_tools/pcie_probe > "$OUT/pcie_probe.log" 2>&1; cat "$OUT/pcie_probe.log"
+hipcc --offload-arch=gfx950 -O3 -o sdr-iq-visualizer_amd/build_tools/pcie_probe experiments/probes/pcie_probe.hip 2>/dev/null && ./sdr-iq-visualizer_amd/build_tools/pcie_probe > "$OUT/pcie_probe.log" 2>&1; cat "$OUT/pcie_probe.log"
 fi
 echo "== per-row measurements at the numpy boundary"; python3 tools/feat_host_probe.py > "$OUT/feat_host_probe.log" 2>&1; tail -2 "$OUT/feat_host_probe.log"
 echo "== bench.py under torch.distributed.run, one rank (the nccl group formed and proven)"
