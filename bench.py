@@ -348,6 +348,26 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
                     report = plan.last_placement
                 warm_up_by_time(lambda: plan.exec_device_timed(d_gen.value, n_frames, d_out.value, 1, frame_stride=stride))
                 ms = plan.exec_device_timed_each(d_gen.value, n_frames, d_out.value, reps, frame_stride=stride)
+                fused = plan.fused_status()
+            other = None
+            if nfft == 65536:
+                # N = 65536 has two forms with bit-identical rows; the default plan above took one of them —
+                # the other one timed the same way beside it, and the rows of both compared
+                import numpy as np
+                picks = sorted({0, n_frames // 3, n_frames - 1})
+                keep = np.empty((len(picks), nfft), np.float32)
+                for i, r in enumerate(picks):
+                    _ffi.check(lib.sdrk_memcpy_d2h(dev, keep[i].ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out.value + r * nfft * 4), nfft * 4))
+                with SpectrumPlan(nfft, window=window, device=dev, fused64k=not fused["launches"]) as alt:
+                    warm_up_by_time(lambda: alt.exec_device_timed(d_gen.value, n_frames, d_out.value, 1, frame_stride=stride))
+                    ms_alt = alt.exec_device_timed_each(d_gen.value, n_frames, d_out.value, reps, frame_stride=stride)
+                    alt.sync()
+                again = np.empty_like(keep)
+                for i, r in enumerate(picks):
+                    _ffi.check(lib.sdrk_memcpy_d2h(dev, again[i].ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out.value + r * nfft * 4), nfft * 4))
+                other = {"form": "two tiled launches (fft_tiled2.hip)" if fused["launches"] else "one persistent launch (fft_fused64k.hip)",
+                         "ms": round(_median(ms_alt), 3), "ms_min": round(min(ms_alt), 3), "ms_max": round(max(ms_alt), 3),
+                         "rows_identical_to_the_default_form": bool(np.array_equal(keep, again)), "rows_compared": picks}
         finally:
             lib.sdrk_dev_free(dev, d_out)
     finally:
@@ -360,6 +380,10 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
             "frame_Msamples_per_s": round(n_frames * nfft / t / 1e6, 1),
             "algorithmic_bytes": algo, "algorithmic_formula": "8*L + 4*rows*N",
             "GBps": round(algo / t / 1e9, 1), "frac": round(algo / t / 1e9 / HBM_PEAK_GBPS, 4),
+            **({} if nfft != 65536 else {
+                "form": "one persistent launch, intermediate in each XCD's L2 (fft_fused64k.hip)" if fused["launches"]
+                        else "two tiled launches (fft_tiled2.hip)",
+                "persistent_launches": fused["launches"], "fell_back_to_tiled": fused["fallen_back"], "other_form": other}),
             "warmup": "the plan's own transform for >= 100 ms before the timed launches (an idle device needs tens of ms of load "
                       "to reach its sustained shader clock: tools/cfg_steady.py)",
             "scratch_placement": None if report is None else {
@@ -854,11 +878,21 @@ def main():
     per_rank = None
     if dist is not None:
         # every rank's own median launch and wall time, so that a straggler (placement level, clocks) shows in the line
-        mine = torch.tensor([_median(list(each_ms)), elapsed * 1e3 / args.steps], device=red_dev, dtype=torch.float64)
+        # ... beside the placement level each rank's buffer pair was probed at (which pairing a process gets is a
+        # lottery; a rank whose launches are slow by what its probe already showed drew a slow pair, it is not a scaling loss)
+        probed = [float(v) for v in probe_ms if float(v) > 0]
+        mine = torch.tensor([_median(list(each_ms)), elapsed * 1e3 / args.steps,
+                             float(probe_ms[int(chosen.value)]) if probed else 0.0, min(probed) if probed else 0.0,
+                             max(probed) if probed else 0.0, float(len(probed))], device=red_dev, dtype=torch.float64)
         everyone = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine, group=grp)
         per_rank = {"launch_ms_median": [round(float(v[0]), 4) for v in everyone],
-                    "wall_ms_per_step": [round(float(v[1]), 4) for v in everyone]}
+                    "wall_ms_per_step": [round(float(v[1]), 4) for v in everyone],
+                    "placement_probe_ms": {"chosen": [round(float(v[2]), 4) for v in everyone],
+                                           "fastest_candidate": [round(float(v[3]), 4) for v in everyone],
+                                           "slowest_candidate": [round(float(v[4]), 4) for v in everyone],
+                                           "candidates_timed": [int(v[5]) for v in everyone],
+                                           "frames_per_probe": "one launch over the rank's own frames (0 = plain allocation, nothing probed)"}}
         t = torch.tensor([elapsed, kernel_ms], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
         elapsed, kernel_ms = float(t[0]), float(t[1])

@@ -2,13 +2,13 @@
 # Round-6 experiment build (this container, no GPU needed): libsdrk.so whose fused N = 65536 kernel is compiled with
 # -DSDRK_FUSED_EXPERIMENT (the policy sweep of fft_fused64k.hip: workgroups per CU, cache-policy bits of the streamed accesses,
 # the timing-only NOWAIT form — chosen per process from SDRK_FU_* environment variables).  Every other object is the product's.
-#   experiments/fused64k_policy/build.sh            -> sdr-iq-visualizer_amd/lib_fuexp/libsdrk.so      (ring depth 2)
-#   experiments/fused64k_policy/build.sh 4          -> sdr-iq-visualizer_amd/lib_fuexp_d4/libsdrk.so   (ring depth 4)
+#   experiments/fused64k_policy/build.sh            -> sdr-iq-visualizer_amd/lib_fuexp/libsdrk.so      (ring depth 1, the product's)
+#   experiments/fused64k_policy/build.sh 2          -> sdr-iq-visualizer_amd/lib_fuexp_d2/libsdrk.so   (ring depth 2)
 set -e
-D=${1:-2}
+D=${1:-1}
 cd "$(dirname "$0")/../../sdr-iq-visualizer_amd/csrc"
 make -s -j8
-NAME=fuexp${FU_NAME_SUFFIX:-}; [ "$D" != 2 ] && NAME=${NAME}_d$D
+NAME=fuexp${FU_NAME_SUFFIX:-}; [ "$D" != 1 ] && NAME=${NAME}_d$D
 mkdir -p ../build_$NAME ../lib_$NAME
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -ffp-contract=on -Wall -Wno-unused-function \
     -DSDRK_FUSED_EXPERIMENT -DFU_RING_SLOTS_N=$D ${FU_EXTRA_FLAGS:-} -c fft_fused64k.hip -o ../build_$NAME/fft_fused64k.o

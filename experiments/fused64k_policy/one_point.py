@@ -22,7 +22,7 @@ d_in, d_b = ctypes.c_void_p(), ctypes.c_void_p()
 _ffi.check(lib.sdrk_dev_alloc(0, samples * 8, ctypes.byref(d_in)))
 _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 4, ctypes.byref(d_b)))
 _ffi.check(lib.sdrk_synth_fill(0, 3, 0, (samples + 4095) // 4096, 4096, d_in, None))
-with SpectrumPlan(n, window="hann", fused64k=(kind == "fused")) as p:
+with SpectrumPlan(n, window="hann", fused64k=(kind == "fused")) as p:   # False = the two tiled launches
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) < 0.04:
         p.exec_device_timed(d_in.value, nf, d_b.value, 1, frame_stride=hop)

@@ -51,7 +51,7 @@ def timed(plan, d_out, warm_ms=60.0, k=12):
 
 rows = min(nf, 48)
 ref = []
-with SpectrumPlan(n, window="hann") as p:
+with SpectrumPlan(n, window="hann", fused64k=False) as p:
     med, mn = timed(p, d_a)
     print(json.dumps({"kernel": "tiled (two launches)", "frames": nf, "hop": hop, "median_ms": round(med, 4), "min_ms": round(mn, 4),
                       "library": _ffi.library_path()}), flush=True)

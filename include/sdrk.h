@@ -124,10 +124,15 @@ int sdrk_host_is_pinned(const void* h_ptr, size_t bytes);
 #define SDRK_MAX_LOG2_NFFT 22
 int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind,
                      const float* window, float eps, int shift, sdrk_plan** out);
-/* Same with option flags.  SDRK_PLAN_FUSED64K (nfft = 65536 only): run the transform as ONE persistent
- * launch whose per-frame intermediate stays in each XCD's L2 (fft_fused64k.hip) instead of the two
- * tiled launches — an experiment kept for A/B work (less HBM traffic, but slower: DESIGN.md §4.4). */
+/* Same with option flags.  nfft = 65536 has two forms: ONE persistent launch whose per-frame intermediate stays in each
+ * XCD's L2 (fft_fused64k.hip), and the two tiled launches through a scratch buffer (fft_tiled2.hip); bit-identical rows.
+ * Without a flag a plan takes the persistent launch for calls of 512 frames or more (BASELINE config 3: 3.9 ms against
+ * 5.0 ms) and the two launches below that (they are faster there: the persistent grid costs ~30 us to set up); if a persistent launch ever reports a failed hand-over (its
+ * workgroups must all be resident at once — another process's kernels can prevent that), the call returns SDRK_ERR_HIP and
+ * the plan takes the two launches from then on.  SDRK_PLAN_FUSED64K: the persistent launch for every call (A/B work, tests).
+ * SDRK_PLAN_TILED64K: never the persistent launch (a device shared with other processes' long-running kernels). */
 #define SDRK_PLAN_FUSED64K 0x1u
+#define SDRK_PLAN_TILED64K 0x8u
 /* SDRK_PLAN_OVERLAP_PASSES (power-of-two nfft >= 2^15): run the row pass of chunk i on a second stream beside the
  * col pass of chunk i + 1, each on its own half of the scratch and on its own share of the CUs.  Bit-identical
  * rows; kept for A/B work like the flag above — measured 20-35 % SLOWER than the serial two-launch form on
@@ -142,6 +147,10 @@ int sdrk_plan_create(int device, int nfft, size_t max_batch, int window_kind,
 int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
                         const float* window, float eps, int shift, unsigned flags, sdrk_plan** out);
 int sdrk_plan_staging_probe(const sdrk_plan* plan, float* probe_ms, int capacity, int* n);
+/* nfft = 65536 plans: how many persistent (fused) launches the plan has made so far, and whether one of them reported a
+ * failed hand-over so that the plan now takes the two tiled launches (see SDRK_PLAN_FUSED64K above).  Either pointer may be
+ * NULL.  Other plans: 0 / 0. */
+int sdrk_plan_fused_status(const sdrk_plan* plan, unsigned* launches, int* fallen_back);
 /* Large-frame plans (nfft >= 2^15) keep their two-pass intermediate in a scratch buffer, and — like the resident
  * input / output pair, see sdrk_dev_alloc_stream_pair — their speed depends a few per cent on WHERE that buffer
  * landed relative to the data (N = 65536 STFT over the same buffers with six different scratch allocations:

@@ -38,6 +38,7 @@ FEAT_ARGMAX, FEAT_PEAK_COUNT, FEAT_OCCUPIED_BINS = 11, 12, 13
 PLAN_FUSED64K = 0x1
 PLAN_OVERLAP_PASSES = 0x2
 PLAN_TUNE_STAGING = 0x4
+PLAN_TILED64K = 0x8
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # SDRK_LIB: developer override (A/B builds made by tools/variant.sh); the product loads lib/libsdrk.so
@@ -71,6 +72,7 @@ SYMBOLS = [
     ("sdrk_plan_create_ex", c_int,
      [c_int, c_int, c_size_t, c_int, c_void_p, c_float, c_int, c_uint32, POINTER(c_void_p)]),
     ("sdrk_plan_staging_probe", c_int, [c_void_p, POINTER(c_float), c_int, POINTER(c_int)]),
+    ("sdrk_plan_fused_status", c_int, [c_void_p, POINTER(c_uint32), POINTER(c_int)]),
     ("sdrk_plan_tune_scratch", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, POINTER(c_float),
                                        POINTER(c_int)]),
     ("sdrk_placement_report", c_int, [POINTER(c_float), POINTER(c_int), POINTER(c_float), POINTER(c_float), POINTER(c_float)]),

@@ -20,6 +20,12 @@
 #endif
 #undef SDRK_PACKED_CF
 #define SDRK_PACKED_CF SDRK_F1_PACKED_CF
+// With SDRK_PACKED_CF = 0 here, sdrk::cf / cmul / radix16 / f4k_transform are defined differently in this translation unit than
+// in every other one.  That is sound only because device code is compiled and linked per file; with relocatable device code
+// (-fgpu-rdc) or device LTO the two definitions would be merged silently.  (csrc/Makefile: neither flag, by design.)
+#if defined(__CLANG_RDC__) && !SDRK_F1_PACKED_CF
+#error "fft4096_features.hip redefines sdrk::cf for this file only: do not build it with -fgpu-rdc (one-definition rule)"
+#endif
 #include "fft4096_core.h"
 #include "row_features_core.h"
 

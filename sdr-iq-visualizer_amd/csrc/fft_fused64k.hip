@@ -4,8 +4,7 @@
 // Same arithmetic as the two launches of fft_tiled2.hip for 256 x 256 (col pass: DFT-256 down 16-wide column
 // tiles, times W_N^(m k3); row pass: DFT-256 along 16 adjacent rows, fftshift, log epilogue) and the same
 // code for both (fft_lds_core.h) — bit-identical results — but the 512 KiB complex64 intermediate of a frame
-// lives in a two-slot ring inside ONE XCD's 4 MiB L2 instead of crossing the fabric twice: 12 B/sample of HBM
-// traffic instead of 28.
+// lives in a one-slot ring inside ONE XCD's 4 MiB L2 instead of crossing the fabric twice.
 //
 // Roles.  The workgroups of the persistent grid (3 per CU, 256 threads) organise themselves into SETS of 32
 // that share an L2: every workgroup reads its XCC id (s_getreg HW_REG_XCC_ID — HIP promises nothing about
@@ -17,24 +16,32 @@
 // current transform and — for the overlapped frames of an STFT — re-uses the samples two consecutive frames
 // share (the software pipeline of col_pass_kernel<.., FIXED, SH>).
 //
-// Flow control inside a set (frame number s of the run, ring slot s % D):
-//   col_done[member 0..15][wave 0..3]   = s + 1 once that wave's stores of frame s are in the L2
-//   row_done[member 0..15][wave 0..3]   = s + 1 once that wave's loads of frame s have returned
-//   a row workgroup starts frame s when all 64 col_done words are > s; a col workgroup stores frame s when all
-//   64 row_done words are > s - D.  Waits only point backwards in s, so there is no cycle; every spin is
-//   bounded, and a timeout (a set that never became complete because some of its members were not resident)
-//   raises the error word instead of hanging — the host then reports the launch as failed.
+// Hand-over inside a set (frame number s of the run, ring slot s % D; D = 1).  The ring is laid out in 16 x 16 blocks
+// (scratch_index): block (k3 tile q, column tile c) is written by col workgroup c ALONE — its q-th store — and read by
+// row workgroup q ALONE — its c-th load.  So the dependencies are point to point and the hand-over is PROGRESSIVE:
+//   col_done[c][wave 0..3] = s + 1   once that wave's stores of frame s are in the L2
+//   row_done[q][wave 0..3] = s + 1   once that wave's loads of frame s have returned
+//   a row wave issues its load c as soon as col_done[c][*] > s; a col wave issues its store q as soon as
+//   row_done[q][*] > s - D.  Every wave polls for itself (one 64-lane load covers the partner role's 64 words) and
+//   issues what has become possible, in whatever order the partners finish; nobody waits for all sixteen partners
+//   before touching the first block, and there is no workgroup barrier in the hand-over.
+// Waits only point backwards in s, so there is no cycle; every spin is bounded, and a timeout (a set that never
+// became complete because some of its members were not resident) raises the error word instead of hanging — the
+// host then reports the launch as failed.
 //
-// Visibility inside one XCD: a producer's plain stores are complete in the shared L2 once its
-// `s_waitcnt vmcnt(0)` returns; it then publishes with an agent-scope relaxed atomic store.  The consumer polls
-// with agent-scope loads and reads the ring with sc1 loads, which bypass its CU's L1 and are served by that same
+// Visibility inside one XCD: a producer's plain stores are complete in the shared L2 once its `s_waitcnt vmcnt(0)`
+// returns; it then publishes with a PLAIN store (st_flag below: the flag stays in that L2).  The consumer polls with
+// agent-scope (sc1) loads and reads the ring with sc1 loads, which bypass its CU's L1 and are served by that same
 // L2.  No L2 write-back is needed because producer and consumer were verified, by XCC id, to share the L2.
 //
-// Measured (MI355X, 4096 packed Hann frames): 2.24 ms against 1.33 ms for the two tiled launches, so this stays an
-// explicit opt-in (SDRK_PLAN_FUSED64K).  With every wait removed (wrong results, timing only) the same kernel
-// takes 1.19 ms: even a free hand-over would gain 10 % — both passes already run near 6 TB/s of streamed bytes,
-// the in-L2 ring traffic costs the XCD about what the fabric traffic cost, and the transforms of the two roles
-// compete for the same LDS.  The hand-over itself (agent-scope flag, poll, ring depth 2) costs the rest.
+// Measured (MI355X, round 6, profiles/r06/fused64k_policy.md): 4096 packed Hann frames 1.04 ms against 1.26 ms for the two
+// tiled launches; BASELINE config 3 (18 749 frames, hop 32768) 3.94 ms against 5.0 ms.  Rounds 1-5 had it at 2.2-2.4 ms /
+// 8.7 ms: the flags were agent-scope stores, which write through and DROP the line from the L2, so every poll went to the
+// fabric.  What the ring costs the fabric depends on how much of the L2 it takes (WRITE_SIZE per 4096 packed frames, 1.07 GB
+// of rows: 3 sets x 2 slots 3.38 GB, 3 x 1 1.50 GB, 1 x 2 with write-through row stores 1.10 GB) — but the kernel is not bound
+// there: with all three sets of an XCD aliased onto one 1 MiB ring and every wait compiled out (traffic exactly 1.0 x the
+// algorithmic bytes) it still takes 1.08 ms.  What bounds it is the cycle of a set: col store -> flag -> row load -> flag,
+// about 5 us per frame against 2.8 us of work per workgroup and frame (phase trace, same file), with three frames in flight per XCD.
 #include "fft_lds_core.h"
 
 namespace sdrk {
@@ -43,13 +50,27 @@ constexpr int FU_THREADS = 256;
 constexpr int FU_N = 65536;
 constexpr int FU_A = 256;                  // = M
 #ifndef FU_RING_SLOTS_N
-#define FU_RING_SLOTS_N 1
+#define FU_RING_SLOTS_N 1                  // depth 2 costs more L2 (write-backs of dead ring lines) than the overlap it allows gains
 #endif
+// Experiment switches (experiments/fused64k_policy/, never defined in the product build; all need -DSDRK_FUSED_EXPERIMENT):
+//   FU_KNOCK     timing only, wrong results; bits: 1 every workgroup a col workgroup, 2 every one a row workgroup, 4 no ring
+//                traffic, 8 no transforms, 16 no input loads, 32 no output stores
+//   FU_ALIAS_RING  timing only (with NOWAIT): every set of an XCD uses the same ring
+//   FU_TRACE     100 MHz timestamps of the phases of every workgroup of sets 0 and 7, first 96 frames, written behind the
+//                output rows (the caller allocates 1 MiB more): [set sel 2][member 32][frame 96][slot 8] unsigned
 #if !defined(SDRK_FUSED_EXPERIMENT) || !defined(FU_KNOCK)
 #undef FU_KNOCK
-#define FU_KNOCK 0   // experiment builds only (timing, wrong results): 1 every workgroup a col workgroup, 2 every one a row workgroup,
-#endif               // 3 no ring traffic, 4 no transforms
-constexpr int FU_SLEEP = 4;                // x 64 clocks between two polls of a wave
+#define FU_KNOCK 0
+#endif
+#if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_TRACE)
+#define FU_T(slot)                                                                                                    \
+    do {                                                                                                              \
+        if (tr_on && tid == 0 && s < 96u)                                                                             \
+            tr_base[((size_t)tr_sel * 96 + s) * 8 + (slot)] = (unsigned)__builtin_amdgcn_s_memrealtime();              \
+    } while (0)
+#else
+#define FU_T(slot) do { } while (0)
+#endif
 constexpr int FU_RING_SLOTS = FU_RING_SLOTS_N;   // D; x 512 KiB per set, three sets per XCD
 constexpr int FU_MAX_XCD = 16;
 constexpr int FU_MAX_SETS = 64;            // dense set numbers (grid / 32 <= this)
@@ -78,39 +99,29 @@ __device__ __forceinline__ void st_flag(unsigned* p, unsigned v) {
     asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
-// Every lane polls one of the 64 words until all of them are >= want.  Wave-uniform result; false = timeout or
-// the error flag was raised by somebody else (the caller leaves the kernel).
-__device__ __forceinline__ bool wave_wait_all(const unsigned* words, unsigned want, unsigned* ctrl, unsigned site) {
-    const int lane = threadIdx.x & 63;
-    for (unsigned spins = 0;; ++spins) {
-        const unsigned v = ld_agent(words + lane);
-        if (__builtin_amdgcn_ballot_w64(v < want) == 0) break;
-        if (spins > FU_SPIN_LIMIT || ld_agent(ctrl + 1)) {
-            if (lane == 0 && !ld_agent(ctrl + 1)) {   // first reporter leaves a record
-                ctrl[2] = (unsigned)(words - ctrl); ctrl[3] = v; ctrl[4] = want; ctrl[5] = site;
-                st_agent(ctrl + 1, 1u);
-            }
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(FU_SLEEP);
-    }
-    asm volatile("" ::: "memory");   // nothing that follows may be hoisted above the poll
-    return true;
+// One poll of the partner role's 64 flag words ([workgroup c][wave 0..3]).  Bit 4c of the result: all four waves of partner
+// workgroup c have published >= want.  Wave-uniform.
+__device__ __forceinline__ unsigned long long ready_groups(const unsigned* words, unsigned want) {
+    const unsigned f = ld_agent(words + (threadIdx.x & 63));
+    unsigned long long ok = __builtin_amdgcn_ballot_w64(f >= want);
+    ok &= ok >> 1;
+    ok &= ok >> 2;
+    asm volatile("" ::: "memory");   // no access of the ring may be hoisted above the poll that allows it
+    return ok & 0x1111111111111111ull;
 }
-
-// Workgroup-wide form: wave 0 polls, everybody learns the outcome through LDS (two barriers).  Measured per 4096
-// frames: every wave polling on its own 3.6 / 3.2 / 2.8 ms with s_sleep 1 / 16 / 64 between polls, wave 0 only
-// (s_sleep 4) 2.2 ms: agent-scope loads are served behind the L2, and hundreds of waves re-reading the same
-// lines compete with the data.
-__device__ __forceinline__ bool wg_wait_all(const unsigned* words, unsigned want, unsigned* ctrl, unsigned site, unsigned* sh) {
-    if (threadIdx.x < 64) {
-        const bool ok = wave_wait_all(words, want, ctrl, site);
-        if (threadIdx.x == 0) *sh = ok ? 1u : 0u;
+// Between two polls that made no progress.  false: give up (timeout, or somebody else raised the error flag); wave-uniform.
+__device__ __forceinline__ bool prog_spin(unsigned& spins, bool progressed, const unsigned* words, unsigned want, unsigned* ctrl,
+                                          unsigned site) {
+    if (progressed) return true;
+    if ((++spins & 31u) == 0u && (spins > FU_SPIN_LIMIT || ld_agent(ctrl + 1))) {
+        if ((threadIdx.x & 63) == 0 && !ld_agent(ctrl + 1)) {   // first reporter leaves a record
+            ctrl[2] = (unsigned)(words - ctrl); ctrl[3] = spins; ctrl[4] = want; ctrl[5] = site;
+            st_agent(ctrl + 1, 1u);
+        }
+        return false;
     }
-    __syncthreads();
-    const bool ok = *sh != 0;
-    __syncthreads();
-    return ok;
+    __builtin_amdgcn_s_sleep(1);
+    return true;
 }
 
 // IN_AUX / OUT_AUX: cache-policy bits of the streamed input loads and row stores (buffer aux: 1 = sc0, 2 = nt, 16 = sc1); NOWAIT
@@ -166,7 +177,6 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
     unsigned* __restrict__ col_done = ctrl + 256 + (size_t)g * 128;
     unsigned* __restrict__ row_done = col_done + 64;
 #if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_ALIAS_RING)
-    // timing only (with NOWAIT): every set of an XCD uses the SAME ring — what full occupancy over one L2-resident ring would cost
     float2* __restrict__ my_ring = ring + (size_t)sh_role[2] * D * FU_N;
 #else
     float2* __restrict__ my_ring = ring + (size_t)g * D * FU_N;
@@ -176,7 +186,12 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
     if (f_begin >= f_end) return;
 
     const unsigned pos = member & 15;
-    const bool is_col = FU_KNOCK == 1 ? true : FU_KNOCK == 2 ? false : member < 16;
+#if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_TRACE)
+    const bool tr_on = g == 0 || g == 7;
+    const int tr_sel = (g == 0 ? 0 : 32) + (int)member;
+    unsigned* __restrict__ tr_base = reinterpret_cast<unsigned*>(static_cast<float*>(out_raw) + (size_t)n_frames * FU_N);
+#endif
+    const bool is_col = (FU_KNOCK & 1) ? true : (FU_KNOCK & 2) ? false : member < 16;
     if (is_col) {
         // ---------------- col workgroup of tile position `pos` ----------------
         const int fr = tid & 15, tau = tid >> 4;
@@ -207,30 +222,52 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
             const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + (live ? f : f_begin) * frame_stride, live ? (unsigned)(FU_N * 8) : 0u);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (q >= q0) x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, IN_AUX));
+                if (q >= q0) {
+                    if ((FU_KNOCK & 16) && !(eps < -1e30f)) { x[q] = v2f{(float)f * 1e-3f + (float)tid, (float)q}; continue; }
+                    x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, IN_AUX));
+                }
         };
         const int so = scratch_index(tau, m, M);
         v2f xa[16], xb[16];
         issue_from(f_begin, xa, 0);
         for (size_t f = f_begin; f < f_end; ++f) {
             const unsigned s = (unsigned)(f - f_begin);
+            FU_T(0);
             issue_from(f + 1, xb, 16 - SH);
             cf v[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = HAS_WINDOW ? cf{xa[q].x, xa[q].y} * wreg[q] : cf{xa[q].x, xa[q].y};
-            if (FU_KNOCK != 4) lds_fft_core<8, 16>(v, lds_all, fr, tau, tw);
-            // the ring slot must have been read by every row workgroup (frame s - D)
-            if (!NOWAIT && s >= (unsigned)D && !wg_wait_all(row_done, s - D + 1, ctrl, 1, sh_role)) return;
-            const __amdgpu_buffer_rsrc_t ro = frame_rsrc(my_ring + (size_t)(s % D) * FU_N, (unsigned)(FU_N * 8));
-            if (FU_KNOCK != 3 || eps < -1e30f) {
+            if (!(FU_KNOCK & 8)) lds_fft_core<8, 16>(v, lds_all, fr, tau, tw);
+            FU_T(1);
+            v2f zz[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf z = cmul(v[rev16(q)], bw[q]);
-                const v2f sv = {z.x, z.y};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sv), ro, so * 8, scratch_index(T * q, 0, M) * 8, 0);
+                zz[q] = v2f{z.x, z.y};
             }
+            FU_T(2);
+            // store q goes to row workgroup q alone: it may be issued once THAT workgroup has read frame s - D
+            const __amdgpu_buffer_rsrc_t ro = frame_rsrc(my_ring + (size_t)(s % D) * FU_N, (unsigned)(FU_N * 8));
+            {
+                unsigned long long pending = 0x1111111111111111ull;
+                unsigned spins = 0;
+                while (pending) {
+                    const unsigned long long go =
+                        (NOWAIT || s < (unsigned)D) ? pending : (ready_groups(row_done, s - D + 1) & pending);
+                    if (!(FU_KNOCK & 4) || eps < -1e30f) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            if ((go >> (4 * q)) & 1ull)
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, zz[q]), ro, so * 8,
+                                                                      scratch_index(T * q, 0, M) * 8, 0);
+                    }
+                    pending &= ~go;
+                    if (pending && !prog_spin(spins, go != 0, row_done, s - D + 1, ctrl, 1)) return;
+                }
             }
+            FU_T(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's ring stores are in the L2
+            FU_T(4);
             if ((tid & 63) == 0) st_flag(col_done + pos * 4 + wave, s + 1);
 #pragma unroll
             for (int q = 0; q < 16; ++q) xa[q] = q < 16 - SH ? xa[q + SH] : xb[q];
@@ -246,19 +283,41 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
         const int e0 = scratch_index(fr, rt, M);
         for (size_t f = f_begin; f < f_end; ++f) {
             const unsigned s = (unsigned)(f - f_begin);
-            if (!NOWAIT && !wg_wait_all(col_done, s + 1, ctrl, 2, sh_role)) return;
+            FU_T(0);
+            // load c comes from col workgroup c alone: it may be issued once THAT workgroup has stored frame s.
+            // sc1: served by this XCD's L2, never by this CU's (possibly stale) L1
             const __amdgpu_buffer_rsrc_t ri = frame_rsrc(my_ring + (size_t)(s % D) * FU_N + (size_t)k3_0 * M, (unsigned)(16 * M * 8));
+            v2f xx[16];
+            {
+                unsigned long long pending = 0x1111111111111111ull;
+                unsigned spins = 0;
+#if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_TRACE)
+                bool first = true;
+#endif
+                while (pending) {
+                    const unsigned long long go = NOWAIT ? pending : (ready_groups(col_done, s + 1) & pending);
+#if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_TRACE)
+                    if (first && go) { FU_T(1); first = false; }
+#endif
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if ((go >> (4 * c)) & 1ull) {
+                            if ((FU_KNOCK & 4) && !(eps < -1e30f)) { xx[c] = v2f{(float)s * 1e-3f + (float)tid, (float)c}; continue; }
+                            xx[c] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, c * T, M) * 8, 16));
+                        }
+                    pending &= ~go;
+                    if (pending && !prog_spin(spins, go != 0, col_done, s + 1, ctrl, 2)) return;
+                }
+            }
+            FU_T(2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's ring loads have returned
+            FU_T(3);
+            if ((tid & 63) == 0) st_flag(row_done + pos * 4 + wave, s + 1);
             cf v[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                if (FU_KNOCK == 3 && !(eps < -1e30f)) { v[c] = cf{(float)s * 1e-3f + (float)tid, (float)c}; continue; }
-                // sc1: served by this XCD's L2, never by this CU's (possibly stale) L1
-                const v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, e0 * 8, scratch_index(0, c * T, M) * 8, 16));
-                v[c] = cf{x.x, x.y};
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's ring loads have returned
-            if ((tid & 63) == 0) st_flag(row_done + pos * 4 + wave, s + 1);
-            if (FU_KNOCK != 4) lds_fft_core<8, 1>(v, lds, 0, rt, tw);
+            for (int c = 0; c < 16; ++c) v[c] = cf{xx[c].x, xx[c].y};
+            if (!(FU_KNOCK & 8)) lds_fft_core<8, 1>(v, lds, 0, rt, tw);
+            FU_T(4);
             __syncthreads();  // all rows are through their last LDS reads: the buffer becomes the transpose tile
             if (EPILOGUE == EPI_LOGPSD) {
                 float* __restrict__ tile = reinterpret_cast<float*>(lds_all);  // [km][17]
@@ -267,6 +326,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
                     const cf z = v[rev16(q)];
                     tile[(rt + T * (q ^ xor_q)) * 17 + fr] = logpsd_db(z.x, z.y, eps);
                 }
+                FU_T(5);
                 __syncthreads();
                 const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float*>(out_raw) + f * (size_t)FU_N + k3_0,
                                                              (unsigned)((FU_N - k3_0) * 4));
@@ -274,6 +334,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float val = tile[(km0 + T * i) * 17 + r];
+                    if ((FU_KNOCK & 32) && !(eps < -1e30f || val == 12345.678f)) continue;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, (km0 * FU_A + r) * 4,
                                                           i * T * FU_A * 4, OUT_AUX);
                 }
@@ -293,6 +354,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
                     o[(size_t)km * FU_A + r] = tile[km * 17 + r];
                 }
             }
+            FU_T(6);
             __syncthreads();  // tile reads done before the next frame's exchanges
         }
     }

@@ -897,6 +897,7 @@ static hipError_t launch_fft_tiled2_serial(const LaunchArgs& a) {
         }
         if (e != hipSuccess) return e;
         float* mip = (a.d_mip && fft_tiled2_has_mip(a.nfft, a.epilogue)) ? a.d_mip + f0 * (size_t)(a.nfft / 16) : nullptr;
+            if (a.mip_written) *a.mip_written = mip != nullptr;
         switch (lm) {
             case 8: e = launch_row<8>(a, dst, nf, A, cap(M), nullptr); break;
             case 9: e = launch_row<9>(a, dst, nf, A, cap(M), nullptr); break;
@@ -989,6 +990,7 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
             if (e == hipSuccess) e = hipStreamWaitEvent(a.stream2, a.ev_col[h], 0);
             if (e != hipSuccess) return e;
             float* mip = (a.d_mip && fft_tiled2_has_mip(a.nfft, a.epilogue)) ? a.d_mip + f0 * (size_t)(a.nfft / 16) : nullptr;
+            if (a.mip_written) *a.mip_written = mip != nullptr;
             e = row_pass(ra, lm, static_cast<char*>(a.d_out) + f0 * (size_t)a.nfft * out_elem, nf, A, cap(M, rcus), cap(1024, rcus), mip);
             if (e == hipSuccess) e = hipEventRecord(a.ev_row[h], a.stream2);
             if (e != hipSuccess) return e;

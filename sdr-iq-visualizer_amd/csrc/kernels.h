@@ -47,6 +47,9 @@ struct LaunchArgs {
     // optional second output of the frame lengths for which fft_tiled2_has_mip() holds: every row max-hold-decimated by 16,
     // float32[n_frames][nfft / 16] as [band = k3 / 16][km] (fft_tiled2.hip, row_pass_wave_kernel<…, MIP>); ignored elsewhere
     float* d_mip = nullptr;
+    // out (host, optional): set by the launcher that honoured d_mip — whoever reads the companion rows later trusts THIS, not
+    // its own idea of which plans write them (a new row-pass variant or build switch cannot then make the two disagree)
+    bool* mip_written = nullptr;
 };
 
 #ifdef __HIPCC__   // device helpers (the host-only sanitizer build of sdrk_api.hip, tests/fake_hip, compiles this header with g++)

@@ -150,8 +150,10 @@ struct sdrk_plan {
     uint32_t* h_small_flag = nullptr;   // completion word the stream writes behind a small call
     void* d_small_flag = nullptr;
     uint32_t small_seq = 0;
-    // N = 65536 fused path (fft_fused64k.hip)
-    bool fused64k = false;
+    // N = 65536 fused path (fft_fused64k.hip).  fused64k: every launch (SDRK_PLAN_FUSED64K); fused_auto: launches of at least
+    // FUSED_AUTO_MIN_FRAMES frames (the default for nfft = 65536), until one reports a failed hand-over (fused_broken, latched).
+    bool fused64k = false, fused_auto = false, fused_broken = false;
+    bool num_cus_overridden = false;   // SDRK_NUM_CUS: the count no longer describes the device's XCDs -> no automatic fused launches
     void* d_fused_ring = nullptr;
     unsigned* d_fused_ctrl = nullptr;
     unsigned* h_fused_err = nullptr;   // pinned mailbox: error word of the last launches
@@ -161,6 +163,10 @@ constexpr size_t SMALL_IN_BYTES = 256 << 10;   // calls up to this much input ta
 constexpr size_t HOST_CHUNK_BYTES = 16 << 20;  // target input bytes per pipelined chunk of sdrk_exec_host
 constexpr size_t ZERO_COPY_MAX_BYTES = 32 << 20;  // calls up to this much input skip the DMA engines (see exec_host_common)
 constexpr unsigned FUSED_MAILBOX = 64;   // entries of 8 words: error flag + debug record
+// Below this many frames a launch of an auto plan takes the two tiled launches: the persistent launch costs about 30 us before
+// its first row (control-block memset, role formation, the ramp of a set's pipeline, the mailbox copy) against 11-18 us, and
+// the two forms cross between 384 and 512 frames, packed or half-overlapped (profiles/r06/fused64k_crossover.log).
+constexpr size_t FUSED_AUTO_MIN_FRAMES = 512;
 
 struct sdrk_waterfall {
     int device = 0;
@@ -172,10 +178,15 @@ struct sdrk_waterfall {
     hipStream_t stream = nullptr;
     void* d_dec = nullptr;    // decimated read-out staging (only grows)
     size_t dec_cap = 0;
-    // two-phase decimated read-out: copy stream, "reduction done" event, a read in flight
+    // two-phase decimated read-out: the reduction AND the copy run on a second stream behind the transform that produced the
+    // rows (ev_dec = "rows written", recorded on `stream`), so the transform stream goes straight on with the next batch;
+    // ev_dec_done = "reduction finished with the ring" (recorded on s_copy): a later write into ring slots [dec_start,
+    // dec_start + dec_rows) waits for it (wf_before_write) — in a running channel those are the newest rows and the next batch
+    // lands elsewhere, so nothing waits.
     hipStream_t s_copy = nullptr;
-    hipEvent_t ev_dec = nullptr;
-    bool read_pending = false;
+    hipEvent_t ev_dec = nullptr, ev_dec_done = nullptr;
+    bool read_pending = false, dec_guard = false;
+    size_t dec_start = 0, dec_rows = 0;
     // frame lengths whose transform can write them (sdrk::fft_tiled2_has_mip): every ring row max-hold-decimated by 16,
     // maxlen * nfft / 16 float32, written by the row pass beside the row itself; mip_ok[slot] = that slot's row came from
     // sdrk_waterfall_append_iq* (rows appended as finished rows have none)
@@ -212,19 +223,59 @@ Roctx& roctx() {
     return r;
 }
 
-int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
-                     int epilogue, hipStream_t stream, float* d_mip);
+// A placement probe's launch lambda maps a failed plan_launch to hipErrorUnknown; plan_launch has then already recorded the
+// specific status and message on this thread — keep them instead of overwriting them with "unknown error".
+thread_local int g_probe_status = SDRK_OK;
+hipError_t probe_launch_result(int st) {
+    if (st == SDRK_OK) return hipSuccess;
+    g_probe_status = st;
+    return hipErrorUnknown;
+}
+int probe_fail(hipError_t e, const char* what) {
+    if (e == hipErrorUnknown && g_probe_status != SDRK_OK) {
+        const int st = g_probe_status;
+        g_probe_status = SDRK_OK;
+        return st;                                     // sdrk_last_error() still holds plan_launch's own text
+    }
+    return fail(SDRK_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
 
-int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
-                int epilogue, hipStream_t stream, float* d_mip = nullptr) {
-    RoctxRange range(p, n_frames, frame_stride, epilogue);
-    return plan_launch_impl(p, d_iq, n_frames, frame_stride, d_out, epilogue, stream, d_mip);
+// Does a launch of n_frames frames of this plan take the persistent N = 65536 kernel?
+bool takes_fused(const sdrk_plan* p, size_t n_frames) {
+    return p->fused64k || (p->fused_auto && !p->fused_broken && n_frames >= FUSED_AUTO_MIN_FRAMES);
+}
+
+// One fused N = 65536 launch at a time per device (see plan_launch_impl).  The events live for the life of the process.
+struct FusedGate {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool recorded = false;
+};
+FusedGate& fused_gate(int device) {
+    static FusedGate gates[64];
+    FusedGate& g = gates[device >= 0 && device < 64 ? device : 0];
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ev && hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) g.ev = nullptr;
+    return g;
 }
 
 int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
-                     int epilogue, hipStream_t stream, float* d_mip) {
+                     int epilogue, hipStream_t stream, float* d_mip, bool* mip_written);
+
+// d_mip / mip_written: see LaunchArgs (kernels.h) — *mip_written tells whether the launch wrote the by-16 companion rows.
+int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
+                int epilogue, hipStream_t stream, float* d_mip = nullptr, bool* mip_written = nullptr) {
+    RoctxRange range(p, n_frames, frame_stride, epilogue);
+    if (mip_written) *mip_written = false;
+    return plan_launch_impl(p, d_iq, n_frames, frame_stride, d_out, epilogue, stream, d_mip, mip_written);
+}
+
+int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
+                     int epilogue, hipStream_t stream, float* d_mip, bool* mip_written) {
     sdrk::LaunchArgs a;
     a.d_mip = d_mip;
+    a.mip_written = mip_written;
     a.d_iq = d_iq;
     a.frame_stride = frame_stride;
     a.d_out = d_out;
@@ -280,11 +331,21 @@ int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t fra
         e = sdrk::launch_fft_lds(a);
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
-    else if (p->fused64k) {
-        e = sdrk::launch_fused64k(a, p->d_fused_ring, p->d_fused_ctrl);
+    else if (takes_fused(p, n_frames) && !d_mip) {
+        // The persistent grid needs every one of its workgroups resident at the same time; two such grids on two streams could
+        // each hold part of the device and wait for the rest.  One at a time per device: each launch waits for the one before.
+        FusedGate& gate = fused_gate(p->device);
+        std::lock_guard<std::mutex> lk(gate.mu);
+        if (gate.ev && gate.last_stream != stream && gate.recorded) e = hipStreamWaitEvent(stream, gate.ev, 0);
+        if (e == hipSuccess) e = sdrk::launch_fused64k(a, p->d_fused_ring, p->d_fused_ctrl);
         if (e == hipSuccess)   // error word, timeout record and the number of sets formed -> pinned mailbox
             e = hipMemcpyAsync(p->h_fused_err + 16 * (p->fused_launches++ % FUSED_MAILBOX), p->d_fused_ctrl,
                                16 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess && gate.ev) {
+            e = hipEventRecord(gate.ev, stream);
+            gate.last_stream = stream;
+            gate.recorded = true;
+        }
         ++p->fused_pending;
     } else if (p->tiled2)
         e = sdrk::launch_fft_tiled2(a);
@@ -309,7 +370,7 @@ RoctxRange::~RoctxRange() {
 
 // After a stream sync: did any fused N=65536 launch report an internal wait timeout?
 int fused_check(sdrk_plan* p) {
-    if (!p->fused64k || !p->h_fused_err) return SDRK_OK;
+    if (!p->h_fused_err || p->fused_pending == 0) return SDRK_OK;
     // mailbox entry: [0] sets formed + 1 (0 = unused entry), [1] error flag, [2..5] record of the first timeout
     const unsigned want = sdrk::fused64k_sets(p->num_cus);
     unsigned bad = 0, rec[16] = {0};
@@ -320,6 +381,7 @@ int fused_check(sdrk_plan* p) {
         if (code) { memcpy(rec, r, sizeof rec); bad = code; }
     }
     p->fused_pending = 0;
+    if (bad && p->fused_auto) p->fused_broken = true;   // an auto plan takes the two tiled launches from here on
     if (bad)
         return fail(SDRK_ERR_HIP, "fused N=65536 kernel reported an internal synchronisation error (code %u; %u of %u sets formed; "
                     "word %u held %u, wanted %u, site %u)", bad, rec[0], want, rec[2], rec[3], rec[4], rec[5]);
@@ -493,13 +555,13 @@ int tune_staging(sdrk_plan* p) {
         for (int c = 0; c < 3 && st == SDRK_OK; ++c) {           // earlier candidates stay allocated: each lands elsewhere
             if (hipMalloc(&cand[c], out_b) != hipSuccess) { st = fail(SDRK_ERR_NOMEM, "device staging"); break; }
             auto launch = [&]() -> hipError_t {
-                return plan_launch(p, s.d_in, per, nfft, cand[c], sdrk::EPI_LOGPSD, p->stream) == SDRK_OK ? hipSuccess : hipErrorUnknown;
+                return probe_launch_result(plan_launch(p, s.d_in, per, nfft, cand[c], sdrk::EPI_LOGPSD, p->stream));
             };
             hipError_t e = hipSuccess;
             if (i == 0 && c == 0) e = placement_warm_up(p->stream, launch, rep);   // (see "placement probes" above)
             float med = 0.0f;
             if (e == hipSuccess) e = placement_time(p->stream, e0, e1, launch, &med);
-            if (e != hipSuccess) { st = fail(SDRK_ERR_HIP, "staging probe failed: %s", hipGetErrorString(e)); break; }
+            if (e != hipSuccess) { st = probe_fail(e, "staging probe failed"); break; }
             p->staging_probe_ms[i * 3 + c] = med;
             if (med < p->staging_probe_ms[i * 3 + best]) best = c;
         }
@@ -775,6 +837,7 @@ int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, in
             return fail(SDRK_ERR_INVALID, "buffers do not hold whole frames of the plan's length");
     }
     if (chosen) *chosen = 0;
+    g_placement = PlacementReport();                  // whatever happens below, sdrk_placement_report never describes an older call
     if (candidates < 1) candidates = 1;
     if (candidates > 16) candidates = 16;
     int st = check_device(device);
@@ -809,7 +872,7 @@ int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, in
     auto launch_on = [&](void* out) {
         return [&, out]() -> hipError_t {
             if (plan)                                 // the plan's own transform over the pair: what will really run
-                return plan_launch(plan, *d_in, plan_frames, (size_t)plan->nfft, out, sdrk::EPI_LOGPSD, s) == SDRK_OK ? hipSuccess : hipErrorUnknown;
+                return probe_launch_result(plan_launch(plan, *d_in, plan_frames, (size_t)plan->nfft, out, sdrk::EPI_LOGPSD, s));
             return sdrk::launch_stream_mix(*d_in, out, pf, prop.multiProcessorCount, s);
         };
     };
@@ -840,7 +903,7 @@ int sdrk_dev_alloc_stream_pair(int device, size_t in_bytes, size_t out_bytes, in
         for (void* p : cand) if (p) (void)hipFree(p);
         (void)hipFree(*d_in);
         *d_in = nullptr;
-        if (e != hipSuccess) return fail(SDRK_ERR_HIP, "placement probe failed: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return probe_fail(e, "placement probe failed");
         return fail(SDRK_ERR_NOMEM, "could not allocate %zu bytes for the output buffer", out_bytes);
     }
     for (int c = 0; c < n_ok; ++c) {
@@ -941,8 +1004,12 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
                         float eps, int shift, unsigned flags, sdrk_plan** out) {
     if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (flags & ~(unsigned)(SDRK_PLAN_FUSED64K | SDRK_PLAN_OVERLAP_PASSES | SDRK_PLAN_TUNE_STAGING))
+    if (flags & ~(unsigned)(SDRK_PLAN_FUSED64K | SDRK_PLAN_OVERLAP_PASSES | SDRK_PLAN_TUNE_STAGING | SDRK_PLAN_TILED64K))
         return fail(SDRK_ERR_INVALID, "unknown plan flags 0x%x", flags);
+    if ((flags & SDRK_PLAN_TILED64K) && (flags & SDRK_PLAN_FUSED64K))
+        return fail(SDRK_ERR_INVALID, "SDRK_PLAN_TILED64K and SDRK_PLAN_FUSED64K exclude each other");
+    if ((flags & SDRK_PLAN_TILED64K) && nfft != 65536)
+        return fail(SDRK_ERR_INVALID, "SDRK_PLAN_TILED64K applies to nfft = 65536 only (got %d)", nfft);
     if ((flags & SDRK_PLAN_OVERLAP_PASSES) && (!is_pow2(nfft) || nfft < (1 << 15)))
         return fail(SDRK_ERR_INVALID, "SDRK_PLAN_OVERLAP_PASSES applies to power-of-two nfft >= 32768 (got %d)", nfft);
     if ((flags & SDRK_PLAN_OVERLAP_PASSES) && (flags & SDRK_PLAN_FUSED64K))
@@ -977,7 +1044,7 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
     p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* env = getenv("SDRK_NUM_CUS")) {   // size the persistent grids as for a smaller device (a partition
         long v = atol(env);                           // mode, or the tests of the grid-smaller-than-work paths); selects no kernel
-        if (v >= 1 && v < p->num_cus) p->num_cus = (int)v;
+        if (v >= 1 && v < p->num_cus) { p->num_cus = (int)v; p->num_cus_overridden = true; }
     }
 
 #define PLAN_TRY(expr)                                                                     \
@@ -1098,9 +1165,14 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
             if (const char* c = getenv("SDRK_OVL_ROW_CUS")) { long v = atol(c); if (v >= 1 && v <= 4096) p->row_cus = (int)v; }
         }
     }
-    if (flags & SDRK_PLAN_FUSED64K) {
-        // Single-launch, XCD-resident form of N = 65536 (fft_fused64k.hip); shares the tables of the tiled path.
-        p->fused64k = true;
+    // Single-launch, XCD-resident form of N = 65536 (fft_fused64k.hip); shares the tables of the tiled path.  Forced by
+    // SDRK_PLAN_FUSED64K; otherwise the default for launches of FUSED_AUTO_MIN_FRAMES frames or more, unless SDRK_PLAN_TILED64K
+    // or SDRK_PLAN_OVERLAP_PASSES asks for the two launches or the device's CUs do not make whole sets (32 workgroups per XCD).
+    const bool fused_auto = nfft == 65536 && !(flags & (SDRK_PLAN_FUSED64K | SDRK_PLAN_TILED64K | SDRK_PLAN_OVERLAP_PASSES)) &&
+                            p->num_cus >= 32 && p->num_cus % 32 == 0 && !p->num_cus_overridden;
+    if ((flags & SDRK_PLAN_FUSED64K) || fused_auto) {
+        p->fused64k = (flags & SDRK_PLAN_FUSED64K) != 0;
+        p->fused_auto = fused_auto;
         PLAN_TRY(hipMalloc(&p->d_fused_ring, sdrk::fused64k_ring_bytes()));
         PLAN_TRY(hipMalloc((void**)&p->d_fused_ctrl, sdrk::fused64k_ctrl_words() * sizeof(unsigned)));
         PLAN_TRY(hipHostMalloc((void**)&p->h_fused_err, FUSED_MAILBOX * 16 * sizeof(unsigned), hipHostMallocDefault));
@@ -1119,6 +1191,13 @@ int sdrk_plan_staging_probe(const sdrk_plan* p, float* probe_ms, int capacity, i
     if (!p || !n) return fail(SDRK_ERR_INVALID, "plan or n is NULL");
     *n = p->staging_probe_n;
     for (int i = 0; i < p->staging_probe_n && i < capacity && probe_ms; ++i) probe_ms[i] = p->staging_probe_ms[i];
+    return SDRK_OK;
+}
+
+int sdrk_plan_fused_status(const sdrk_plan* p, unsigned* launches, int* fallen_back) {
+    if (!p) return fail(SDRK_ERR_INVALID, "plan is NULL");
+    if (launches) *launches = p->fused_launches;
+    if (fallen_back) *fallen_back = p->fused_broken ? 1 : 0;
     return SDRK_OK;
 }
 
@@ -1282,7 +1361,8 @@ int sdrk_plan_tune_scratch(sdrk_plan* p, const void* d_iq, size_t n_frames, size
     int st = check_exec_args(p, d_iq, n_frames, frame_stride, d_out_db);
     if (st != SDRK_OK) return st;
     g_placement = PlacementReport();
-    if (!p->d_scratch || p->scratch_frames == 0 || n_frames == 0) {      // no scratch (one-pass lengths): nothing to place
+    if (!p->d_scratch || p->scratch_frames == 0 || n_frames == 0 || takes_fused(p, n_frames)) {
+        // no scratch on this workload's path (one-pass lengths; the persistent N = 65536 launch): nothing to place
         if (probe_ms) for (int c = 0; c < candidates; ++c) probe_ms[c] = 0.0f;
         return SDRK_OK;
     }
@@ -1299,7 +1379,7 @@ int sdrk_plan_tune_scratch(sdrk_plan* p, const void* d_iq, size_t n_frames, size
     if (e == hipSuccess) e = hipEventCreate(&e1);
     PlacementReport rep;
     auto launch = [&]() -> hipError_t {
-        return plan_launch(p, d_iq, n_frames, frame_stride, d_out_db, sdrk::EPI_LOGPSD, p->stream) == SDRK_OK ? hipSuccess : hipErrorUnknown;
+        return probe_launch_result(plan_launch(p, d_iq, n_frames, frame_stride, d_out_db, sdrk::EPI_LOGPSD, p->stream));
     };
     if (e == hipSuccess) e = placement_warm_up(p->stream, launch, rep);    // (see "placement probes" above)
     int n_ok = 0;
@@ -1341,7 +1421,7 @@ int sdrk_plan_tune_scratch(sdrk_plan* p, const void* d_iq, size_t n_frames, size
     rep.candidates = n_ok;
     rep.chosen = best;
     g_placement = rep;
-    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "scratch placement probe failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return probe_fail(e, "scratch placement probe failed");
     return fused_check(p);
 }
 
@@ -1823,6 +1903,8 @@ int sdrk_waterfall_create(int device, int nfft, int maxlen, sdrk_waterfall** out
     if (e == hipSuccess && sdrk::fft_tiled2_has_mip(nfft, sdrk::EPI_LOGPSD)) {
         // 1/16 of the ring again: the rows max-hold-decimated by 16, written by the transform beside the rows (N >= 2^20)
         e = hipMalloc((void**)&wf->d_mip_ring, (size_t)maxlen * (nfft / 16) * sizeof(float));
+        // -inf everywhere: should a slot ever be read before the transform has written it, a maximum over it is harmless
+        if (e == hipSuccess) e = hipMemsetD32(wf->d_mip_ring, (int)0xFF800000u, (size_t)maxlen * (size_t)(nfft / 16));
         wf->mip_ok.assign((size_t)maxlen, 0);
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&wf->stream, hipStreamNonBlocking);
@@ -1844,6 +1926,7 @@ int sdrk_waterfall_destroy(sdrk_waterfall* wf) {
         (void)hipStreamDestroy(wf->s_copy);
     }
     if (wf->ev_dec) (void)hipEventDestroy(wf->ev_dec);
+    if (wf->ev_dec_done) (void)hipEventDestroy(wf->ev_dec_done);
     if (wf->stream) {
         (void)hipStreamSynchronize(wf->stream);
         (void)hipStreamDestroy(wf->stream);
@@ -1875,6 +1958,18 @@ int sdrk_waterfall_clear(sdrk_waterfall* wf) {
     return SDRK_OK;
 }
 
+// Before `run` ring slots from wf->head are overwritten on wf->stream: if the second stream's reduction may still be reading
+// any of them, the write waits for it.
+static hipError_t wf_before_write(sdrk_waterfall* wf, size_t run) {
+    if (!wf->dec_guard || run == 0) return hipSuccess;
+    const size_t L = (size_t)wf->maxlen;
+    const size_t a0 = wf->head, b0 = wf->dec_start;           // both ranges may wrap: compare slot by modular distance
+    const bool overlap = ((b0 + L - a0) % L) < run || ((a0 + L - b0) % L) < wf->dec_rows;
+    if (!overlap) return hipSuccess;
+    wf->dec_guard = false;                                    // (a stream waits for an event once; later writes are behind it)
+    return hipStreamWaitEvent(wf->stream, wf->ev_dec_done, 0);
+}
+
 static void wf_advance(sdrk_waterfall* wf, size_t rows) {
     wf->head = (wf->head + rows) % (size_t)wf->maxlen;
     wf->count = wf->count + rows > (size_t)wf->maxlen ? (size_t)wf->maxlen : wf->count + rows;
@@ -1893,6 +1988,7 @@ int sdrk_waterfall_append_rows(sdrk_waterfall* wf, const float* rows, size_t n_r
     while (done < n_rows) {
         size_t run = (size_t)wf->maxlen - wf->head;
         if (run > n_rows - done) run = n_rows - done;
+        HIP_TRY(wf_before_write(wf, run));
         HIP_TRY(hipMemcpyAsync(wf->d_ring + wf->head * (size_t)wf->nfft, rows + done * (size_t)wf->nfft,
                                run * row_bytes, hipMemcpyHostToDevice, wf->stream));
         if (!wf->mip_ok.empty()) std::fill(wf->mip_ok.begin() + (long)wf->head, wf->mip_ok.begin() + (long)(wf->head + run), 0);
@@ -1920,12 +2016,14 @@ int sdrk_waterfall_append_iq_device_async(sdrk_waterfall* wf, sdrk_plan* p, cons
         size_t run = (size_t)wf->maxlen - wf->head;
         if (run > n_frames - done) run = n_frames - done;
         // the transform writes its rows straight into the ring slots
-        // ... and, where the row pass can, the by-16 max-hold of each row beside it.  (A plan that cannot — chirp-z, the
-        // fused or the pair-kernel builds — leaves the slots marked as having none.)
-        const bool with_mip = wf->d_mip_ring && p->tiled2 && !p->fused64k && !p->blu_inner;
+        // ... and, where the row pass can, the by-16 max-hold of each row beside it.  Whether it did is reported by the
+        // launcher itself (with_mip); a plan that cannot — chirp-z, N = 65536, the pair-kernel builds — leaves the slots marked
+        // as having none, and max-mode read-outs of those slots reduce the rows themselves.
+        bool with_mip = false;
+        HIP_TRY(wf_before_write(wf, run));
         int st = plan_launch(p, static_cast<const float2*>(d_iq) + done * frame_stride, run, frame_stride,
                              wf->d_ring + wf->head * (size_t)wf->nfft, sdrk::EPI_LOGPSD, wf->stream,
-                             with_mip ? wf->d_mip_ring + wf->head * (size_t)(wf->nfft / 16) : nullptr);
+                             wf->d_mip_ring ? wf->d_mip_ring + wf->head * (size_t)(wf->nfft / 16) : nullptr, &with_mip);
         if (st != SDRK_OK) return st;
         if (!wf->mip_ok.empty()) std::fill(wf->mip_ok.begin() + (long)wf->head, wf->mip_ok.begin() + (long)(wf->head + run), with_mip ? 1 : 0);
         wf_advance(wf, run);
@@ -1987,14 +2085,14 @@ int sdrk_waterfall_read(sdrk_waterfall* wf, float* out, size_t max_rows, size_t*
 
 // the reduction of `rows` ring rows starting at slot `start` to nfft / factor bins each, into wf->d_dec: from the by-16
 // rows when every requested slot has one (max mode, factor a multiple of 16) — 1/16 of the bytes —, else from the rows
-static hipError_t wf_launch_decimate(sdrk_waterfall* wf, size_t start, size_t rows, int factor, int mode) {
+static hipError_t wf_launch_decimate(sdrk_waterfall* wf, size_t start, size_t rows, int factor, int mode, hipStream_t stream) {
     bool mip = wf->d_mip_ring && mode == 0 && factor % 16 == 0;
     for (size_t r = 0; r < rows && mip; ++r) mip = wf->mip_ok[(start + r) % (size_t)wf->maxlen] != 0;
     if (mip)
         return sdrk::launch_decimate_mip(wf->d_mip_ring, wf->nfft, wf->maxlen, (int)start, (int)rows, factor,
-                                         static_cast<float*>(wf->d_dec), wf->stream);
+                                         static_cast<float*>(wf->d_dec), stream);
     return sdrk::launch_decimate_rows(wf->d_ring, wf->nfft, wf->maxlen, (int)start, (int)rows, factor, mode,
-                                      static_cast<float*>(wf->d_dec), wf->stream);
+                                      static_cast<float*>(wf->d_dec), stream);
 }
 
 int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
@@ -2013,7 +2111,7 @@ int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_row
     const size_t bins = (size_t)(wf->nfft / factor);
     int st = grow(wf->device, &wf->d_dec, &wf->dec_cap, rows * bins * sizeof(float));
     if (st != SDRK_OK) return st;
-    hipError_t e = wf_launch_decimate(wf, start, rows, factor, mode);
+    hipError_t e = wf_launch_decimate(wf, start, rows, factor, mode, wf->stream);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "decimate launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpyAsync(out, wf->d_dec, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->stream));
     HIP_TRY(hipStreamSynchronize(wf->stream));
@@ -2035,16 +2133,23 @@ int sdrk_waterfall_read_decimated_begin(sdrk_waterfall* wf, float* out, size_t m
     if (!wf->s_copy) {
         HIP_TRY(hipStreamCreateWithFlags(&wf->s_copy, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&wf->ev_dec, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&wf->ev_dec_done, hipEventDisableTiming));
     }
     const size_t L = (size_t)wf->maxlen;
     const size_t start = (wf->head + L - rows % L) % L;
     const size_t bins = (size_t)(wf->nfft / factor);
+    if (rows * bins * sizeof(float) > wf->dec_cap) HIP_TRY(hipStreamSynchronize(wf->s_copy));   // the staging is about to move
     int st = grow(wf->device, &wf->d_dec, &wf->dec_cap, rows * bins * sizeof(float));
     if (st != SDRK_OK) return st;
-    hipError_t e = wf_launch_decimate(wf, start, rows, factor, mode);
-    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "decimate launch failed: %s", hipGetErrorString(e));
+    // the rows are complete once everything enqueued on the transform stream so far has run; from there on the second stream
     HIP_TRY(hipEventRecord(wf->ev_dec, wf->stream));
     HIP_TRY(hipStreamWaitEvent(wf->s_copy, wf->ev_dec, 0));
+    hipError_t e = wf_launch_decimate(wf, start, rows, factor, mode, wf->s_copy);
+    if (e != hipSuccess) return fail(SDRK_ERR_HIP, "decimate launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(wf->ev_dec_done, wf->s_copy));
+    wf->dec_start = start;
+    wf->dec_rows = rows;
+    wf->dec_guard = true;
     HIP_TRY(hipMemcpyAsync(out, wf->d_dec, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->s_copy));
     wf->read_pending = true;
     *n_rows = rows;
@@ -2056,6 +2161,7 @@ int sdrk_waterfall_read_decimated_end(sdrk_waterfall* wf) {
     if (!wf->read_pending) return SDRK_OK;
     HIP_TRY(hipSetDevice(wf->device));
     wf->read_pending = false;
+    wf->dec_guard = false;
     HIP_TRY(hipStreamSynchronize(wf->s_copy));
     return SDRK_OK;
 }

@@ -153,7 +153,9 @@ def plan_pinning(n_devices: int, in_bytes: int, pageable_fraction: float, sighti
 # very owners are alive: a fresh array that the allocator happens to put at a recycled address starts from zero.
 _sightings: dict = {}
 _auto_registered: dict = {}          # base address -> bytes, page-locked by _register_for_life
-_not_registrable: set = set()        # base addresses hipHostRegister has refused (overlap with a user registration ...)
+# base address -> weak reference to the owning array whose registration hipHostRegister refused (overlap with a user registration
+# ...).  Tied to that very array: another array the allocator later puts at the same address is tried afresh.
+_not_registrable: dict = {}
 # Re-entrant: a finaliser (undo below) that the cyclic collector runs while this thread is inside a locked region must
 # not deadlock; the finaliser itself does not take the lock at all (dict.pop is atomic under the GIL).
 _auto_lock = threading.RLock()
@@ -200,20 +202,26 @@ def _register_for_life(a: np.ndarray) -> bool:
     with _auto_lock:
         if ptr in _auto_registered:
             return True
-        if ptr in _not_registrable:
-            return False
+        refused = _not_registrable.get(ptr)
+        if refused is not None:
+            if refused() is root:
+                return False
+            del _not_registrable[ptr]           # the refused array is gone; this is another one at a recycled address
         try:
             check(lib().sdrk_host_register(c_void_p(ptr), c_size_t(nbytes)))
         except (ValueError, MemoryError, _ffi.SdrkError):
             if len(_not_registrable) > 256:
                 _not_registrable.clear()
-            _not_registrable.add(ptr)
+            try:
+                _not_registrable[ptr] = weakref.ref(root)
+            except TypeError:                   # (cannot happen for an ndarray; without a reference nothing is remembered)
+                pass
             return False
         _auto_registered[ptr] = nbytes
 
     def undo(p=ptr):
         _auto_registered.pop(p, None)        # no lock: may run from the collector inside a locked region of any thread
-        _not_registrable.discard(p)
+        _not_registrable.pop(p, None)
         try:
             lib().sdrk_host_unregister(c_void_p(p))
         except Exception:                   # noqa: BLE001 - interpreter shutdown

@@ -67,7 +67,7 @@ class SpectrumPlan:
     """
 
     def __init__(self, nfft: int, *, window: WindowArg = None, eps: float = 1e-12,
-                 shift: bool = True, device: int = 0, max_batch: int = 1 << 30, fused64k: bool = False,
+                 shift: bool = True, device: int = 0, max_batch: int = 1 << 30, fused64k: Optional[bool] = None,
                  overlap_passes: bool = False, tune_staging: bool = False):
         nfft = int(nfft)
         pow2 = nfft >= 2 and not (nfft & (nfft - 1))
@@ -85,15 +85,18 @@ class SpectrumPlan:
         self.last_placement: Optional[dict] = None     # report of the last tune_scratch() on this plan
         self._handle = c_void_p()
         wptr = warr.ctypes.data_as(c_void_p) if warr is not None else None
-        # fused64k: the experimental single-launch form of N = 65536; an explicit plan
-        # option, so the path taken is visible in the API and in the plan cache key
-        self.fused64k = bool(fused64k)
+        # fused64k (nfft = 65536 only): None = the library's default (the single persistent launch for calls
+        # of 512 frames or more, the two tiled launches below that), True = the persistent launch for every call, False = never
+        # (sdrk.h SDRK_PLAN_FUSED64K / SDRK_PLAN_TILED64K).  An explicit plan option, so the path is visible in the API.
+        self.fused64k = None if fused64k is None else bool(fused64k)
         # overlap_passes: the two passes of a large frame on two streams (slower, kept for A/B)
         self.overlap_passes = bool(overlap_passes)
         # tune_staging: the numpy boundary's device staging placed at creation (sdrk.h SDRK_PLAN_TUNE_STAGING; measured:
         # no effect at the shipped chunk size)
         self.tune_staging = bool(tune_staging)
-        flags = ((_ffi.PLAN_FUSED64K if self.fused64k else 0) | (_ffi.PLAN_OVERLAP_PASSES if self.overlap_passes else 0) |
+        flags = ((_ffi.PLAN_FUSED64K if self.fused64k else 0) |
+                 (_ffi.PLAN_TILED64K if self.fused64k is False and nfft == 65536 else 0) |
+                 (_ffi.PLAN_OVERLAP_PASSES if self.overlap_passes else 0) |
                  (_ffi.PLAN_TUNE_STAGING if self.tune_staging else 0))
         check(lib().sdrk_plan_create_ex(self.device, nfft, c_size_t(int(max_batch)), kind, wptr,
                                         c_float(self.eps), int(self.shift), flags, byref(self._handle)))
@@ -252,6 +255,13 @@ class SpectrumPlan:
 
     def sync(self) -> None:
         check(lib().sdrk_plan_sync(self.handle))
+
+    def fused_status(self) -> dict:
+        """``nfft = 65536`` plans: ``{"launches": persistent launches made so far, "fallen_back": a launch reported a failed
+        hand-over and the plan now takes the two tiled launches}`` (``sdrk_plan_fused_status``); zeros for other plans."""
+        n, fb = _ffi.c_uint32(0), c_int(0)
+        check(lib().sdrk_plan_fused_status(self.handle, byref(n), byref(fb)))
+        return {"launches": int(n.value), "fallen_back": bool(fb.value)}
 
     def staging_probe(self) -> list:
         """Probe times (ms) of the staging candidates of a ``tune_staging=True`` plan, three per chunk slot; ``[]``

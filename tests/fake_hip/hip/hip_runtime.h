@@ -217,6 +217,11 @@ inline hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t s) {
     fakehip::of(s).push([dst, v, n] { memset(dst, v, n); });
     return hipSuccess;
 }
+inline hipError_t hipMemsetD32(void* dst, int v, size_t count) {
+    fakehip::null_stream().drain();
+    for (size_t i = 0; i < count; ++i) static_cast<int*>(dst)[i] = v;
+    return hipSuccess;
+}
 inline hipError_t hipStreamWriteValue32(hipStream_t s, void* ptr, uint32_t value, unsigned) {
     fakehip::of(s).push([ptr, value] { __atomic_store_n(static_cast<uint32_t*>(ptr), value, __ATOMIC_RELEASE); });
     return hipSuccess;

@@ -96,8 +96,10 @@ class _FakeLib:
 
     def __init__(self, on_register=None, refuse=()):
         self.registered, self.unregistered, self.on_register, self.refuse = [], [], on_register, set(refuse)
+        self.register_calls = []
 
     def sdrk_host_register(self, ptr, nbytes):
+        self.register_calls.append(ptr.value)
         if ptr.value in self.refuse:
             return -3
         if self.on_register:
@@ -130,7 +132,7 @@ def _patched(monkeypatch, fake):
     monkeypatch.setattr(_ffi, "lib", lambda: fake)          # check() reads the error text through _ffi.lib()
     monkeypatch.setattr(h, "_sightings", {})
     monkeypatch.setattr(h, "_auto_registered", {})
-    monkeypatch.setattr(h, "_not_registrable", set())
+    monkeypatch.setattr(h, "_not_registrable", {})
     return h
 
 
@@ -217,6 +219,18 @@ def test_a_refused_registration_falls_back_to_staging(monkeypatch):
         d = h.auto_pin([x], 8, 8 << 30, cores=1)
         assert d.mode == "stage" and "cannot be page-locked" in d.reason
     assert not fake.registered and x.ctypes.data in h._not_registrable
+    assert len(fake.register_calls) == 1                  # asked once, remembered for THIS array
+    # ... but only for that array: another one at the same (recycled) address is tried afresh.  (The allocator cannot be told
+    # where to put it; the table entry of the dead array is moved to the new array's address instead.)
+    addr = x.ctypes.data
+    ref = h._not_registrable.pop(addr)
+    del x
+    assert ref() is None
+    y = np.zeros((64, 4096), dtype=np.complex64)
+    h._not_registrable[y.ctypes.data] = ref                # an entry whose owner is dead, at y's address
+    fake.refuse.clear()
+    modes = [h.auto_pin([y], 8, 8 << 30, cores=1).mode for _ in range(6)]
+    assert "register" in modes and fake.registered == [y.ctypes.data] and y.ctypes.data not in h._not_registrable
 
 
 def test_waterfall_close_is_serialised_with_calls_in_flight(monkeypatch):

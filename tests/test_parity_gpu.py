@@ -1191,7 +1191,7 @@ def test_fused_n65536_agrees_with_two_launch_path(pkg):
     try:
         _ffi.check(lib.sdrk_synth_fill(0, 77, 0, (nf + 1) * 16, 4096, d_in, None))
         fused = SpectrumPlan(n, window="hann", fused64k=True)
-        tiled = SpectrumPlan(n, window="hann")
+        tiled = SpectrumPlan(n, window="hann", fused64k=False)
         a = np.empty(n, dtype=np.float32)
         b = np.empty(n, dtype=np.float32)
         for stride, rows in ((n, nf), (n // 2, 2 * nf - 1)):          # packed frames, then 50 % overlap
@@ -1212,10 +1212,28 @@ def test_fused_n65536_agrees_with_two_launch_path(pkg):
         x = rand_c64(rng, 70, n, scale=4.0)                                # 70 frames: more than the 24 sets, uneven runs
         stream = rand_c64(rng, 1, 40 * (n // 2) + n, scale=4.0)[0]
         for window in (None, "hann"):
-            with SpectrumPlan(n, window=window, fused64k=True) as pf, SpectrumPlan(n, window=window) as pt:
+            with SpectrumPlan(n, window=window, fused64k=True) as pf, SpectrumPlan(n, window=window, fused64k=False) as pt:
                 assert np.array_equal(pf.fft(x), pt.fft(x)), f"complex epilogue, window={window}"
                 assert np.array_equal(pf.spectrum_db(x), pt.spectrum_db(x)), f"log epilogue, window={window}"
                 assert np.array_equal(pf.stft_db(stream, n // 2), pt.stft_db(stream, n // 2)), f"STFT, window={window}"
+                assert pf.fused_status()["launches"] >= 3 and pt.fused_status() == {"launches": 0, "fallen_back": False}
+        # the default plan: the persistent launch for device-resident calls of 512 frames or more, the two tiled launches below
+        # that (and for the 32-frame chunks of the numpy boundary); same rows either way
+        with SpectrumPlan(n, window="hann") as pa, SpectrumPlan(n, window="hann", fused64k=False) as pt:
+            assert np.array_equal(pa.spectrum_db(x), pt.spectrum_db(x))
+            assert pa.fused_status() == {"launches": 0, "fallen_back": False}
+            for rows, want_launches in ((511, 0), (512, 1), (1500, 2)):
+                pa.exec_device(d_in.value, rows, d_a.value, frame_stride=n // 2)
+                pa.sync()
+                pt.exec_device(d_in.value, rows, d_b.value, frame_stride=n // 2)
+                pt.sync()
+                assert pa.fused_status() == {"launches": want_launches, "fallen_back": False}
+                for f in (0, rows // 2, rows - 1):
+                    _ffi.check(lib.sdrk_memcpy_d2h(0, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_a.value + f * n * 4), n * 4))
+                    _ffi.check(lib.sdrk_memcpy_d2h(0, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_b.value + f * n * 4), n * 4))
+                    assert np.array_equal(a, b), f"default plan, {rows} rows, row {f}"
+        with SpectrumPlan(4096) as p4:
+            assert p4.fused_status() == {"launches": 0, "fallen_back": False}
     finally:
         for d in (d_in, d_a, d_b):
             lib.sdrk_dev_free(0, d)
@@ -1238,7 +1256,8 @@ def test_overlapped_passes_agree_with_serial_form(pkg):
         _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_b)))
         try:
             _ffi.check(lib.sdrk_synth_fill(0, 41, 0, (in_samples + 4095) // 4096, 4096, d_in, None))
-            with SpectrumPlan(n, window="hann", overlap_passes=True) as po, SpectrumPlan(n, window="hann") as ps:
+            with SpectrumPlan(n, window="hann", overlap_passes=True) as po, \
+                    SpectrumPlan(n, window="hann", fused64k=False if n == 65536 else None) as ps:
                 for _ in range(2):
                     po.exec_device(d_in.value, rows, d_a.value, frame_stride=stride)
                 po.sync()
@@ -1579,10 +1598,14 @@ def test_c_abi_refuses_invalid_arguments(pkg):
     assert seen >= 70
 
 
-def test_config3_full_size_sampled_rows(pkg):
+@pytest.mark.parametrize("form", ["default", "two_tiled_launches"])
+def test_config3_full_size_sampled_rows(pkg, form):
     """BASELINE.json config 3 at full size: 10 s @ 61.44 Msps = 614 400 000 samples on the device,
     N = 65536, hop = 32768, Hann -> 18 749 rows (9.8 GB through the kernels); rows sampled across the run against the
-    oracle on the numpy-regenerated samples.  The transform walks the stream in chunks of 384 frames (192 MiB of scratch,
+    oracle on the numpy-regenerated samples, for both forms of the transform.  The default plan takes ONE persistent launch
+    (fft_fused64k.hip): 24 sets of 32 workgroups, set g owns the contiguous run of 782 rows from 782 g (the last set 763) —
+    sampled on both sides of the first, second and last run boundary (781 / 782, 1563 / 1564, 17985 / 17986).  The two tiled
+    launches walk the stream in chunks of 384 frames (192 MiB of scratch,
     sdrk_api.hip: plan creation; fft_tiled2.hip: round_chunk) = 48 full chunks + a last one of 317; inside a chunk the
     col pass gives each of its 48 workgroups per tile position a run of 8 consecutive frames (7 in the last chunk, whose
     46th run has 2 frames left and whose 47th and 48th have none).  Sampled: both ends, both sides of the first, second
@@ -1600,16 +1623,20 @@ def test_config3_full_size_sampled_rows(pkg):
     _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_out)))
     try:
         _ffi.check(lib.sdrk_synth_fill(0, 31, 0, gen_frames, 4096, d_in, None))
-        with SpectrumPlan(n, window="hann") as plan:
+        with SpectrumPlan(n, window="hann", fused64k=None if form == "default" else False) as plan:
             plan.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)
             plan.sync()
+            assert plan.fused_status() == {"launches": 1 if form == "default" else 0, "fallen_back": False}
         w = np.hanning(n)
         row = np.empty(n, dtype=np.float32)
         chunk, last0 = 384, 48 * 384                                      # 18432: first row of the 317-frame chunk
         assert rows == last0 + 317
+        run = -(-rows // 24)                                              # 782: rows per set of the persistent launch
+        assert run == 782 and 23 * run == 17986
         picks = (0, 1, 7, 8, 9, 255, 256, 257, chunk - 1, chunk, chunk + 1, 2 * chunk - 1, 2 * chunk, 9000,
                  last0 - 1, last0, last0 + 1, last0 + 6, last0 + 7, last0 + 8,           # run length 7 in the last chunk
-                 last0 + 45 * 7 - 1, last0 + 45 * 7, rows - 1)                            # ... and its short last run
+                 last0 + 45 * 7 - 1, last0 + 45 * 7, rows - 1,                            # ... and its short last run
+                 run - 1, run, 2 * run - 1, 2 * run, 23 * run - 1, 23 * run)              # set boundaries of the persistent launch
         for r in picks:
             _ffi.check(lib.sdrk_memcpy_d2h(0, row.ctypes.data_as(ctypes.c_void_p),
                                            ctypes.c_void_p(d_out.value + r * n * 4), row.nbytes))
@@ -1764,7 +1791,7 @@ def test_scratch_placement_tuning_keeps_results_and_reports_probes(pkg):
     from sdr_iq_visualizer_amd import _ffi
     from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
     lib = _ffi.lib()
-    n, rows, hop = 65536, 500, 32768
+    n, rows, hop = 65536, 600, 32768
     L = n + (rows - 1) * hop
     d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
     _ffi.check(lib.sdrk_dev_alloc(0, ((L + 4095) // 4096) * 4096 * 8, ctypes.byref(d_in)))
@@ -1772,7 +1799,7 @@ def test_scratch_placement_tuning_keeps_results_and_reports_probes(pkg):
     try:
         _ffi.check(lib.sdrk_synth_fill(0, 11, 0, (L + 4095) // 4096, 4096, d_in, None))
         a, b = np.empty((rows, n), np.float32), np.empty((rows, n), np.float32)
-        with SpectrumPlan(n, window="hann") as plan:
+        with SpectrumPlan(n, window="hann", fused64k=False) as plan:   # the two tiled launches: the form that has a scratch
             plan.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)
             plan.sync()
             _ffi.check(lib.sdrk_memcpy_d2h(0, a.ctypes.data_as(ctypes.c_void_p), d_out, a.nbytes))
@@ -1802,6 +1829,13 @@ def test_scratch_placement_tuning_keeps_results_and_reports_probes(pkg):
         with SpectrumPlan(4096) as small:
             probe, chosen = small.tune_scratch(d_in.value, 16, d_out.value, 3)
             assert probe == [0.0, 0.0, 0.0] and chosen == 0 and small.last_placement["candidates_tried"] == 0
+        with SpectrumPlan(n, window="hann") as default:      # 600 rows (>= 512) take the persistent launch: no scratch on that path
+            probe, chosen = default.tune_scratch(d_in.value, rows, d_out.value, 3, frame_stride=hop)
+            assert probe == [0.0, 0.0, 0.0] and chosen == 0 and default.last_placement["candidates_tried"] == 0
+            default.exec_device(d_in.value, rows, d_out.value, frame_stride=hop)
+            default.sync()
+            _ffi.check(lib.sdrk_memcpy_d2h(0, b.ctypes.data_as(ctypes.c_void_p), d_out, b.nbytes))
+            assert np.array_equal(a, b) and default.fused_status()["launches"] == 1
     finally:
         lib.sdrk_dev_free(0, d_in)
         lib.sdrk_dev_free(0, d_out)

@@ -22,7 +22,7 @@ _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 4, ctypes.byref(d_a)))
 _ffi.check(lib.sdrk_dev_alloc(0, nf * n * 4, ctypes.byref(d_b)))
 _ffi.check(lib.sdrk_synth_fill(0, 3, 0, (samples + 4095) // 4096, 4096, d_in, None))
 res = {}
-for name, kw, d_out in (("tiled", {}, d_a), ("fused", {"fused64k": True}, d_b)):
+for name, kw, d_out in (("tiled", {"fused64k": False}, d_a), ("fused", {"fused64k": True}, d_b)):
     with SpectrumPlan(n, window=None if window == "rect" else window, **kw) as p:
         p.exec_device(d_in.value, nf, d_out.value, frame_stride=hop)
         p.sync()
