@@ -419,21 +419,25 @@ def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=24, p
                     got += wf.as_array(max_rows=nb, decimate=nfft // px).shape[0]
                 return got
 
-            slots = [pkg.pinned_empty((batch, px), np.float32) for _ in range(2)]
+            slots = [pkg.pinned_empty((batch, px), np.float32) for _ in range(3)]
 
             def run_pipelined():
-                # the same work with nothing waited for that does not have to be: batch i + 1 is enqueued before batch
-                # i's rows are collected, so its transform runs while they cross PCIe (two-phase decimated read-out)
+                # the same work with nothing waited for that does not have to be: batch i's transform and its read-out (on the
+                # ring's second stream) are enqueued BEFORE batch i - 1's rows are collected — two read-outs in flight — so the
+                # host's wait for rows that are one batch old never leaves the transform stream without the next batch
                 wf.clear()
-                got, pending = 0, False
+                got, in_flight = 0, 0
                 for i, f0 in enumerate(range(0, n_frames, batch)):
                     nb = min(batch, n_frames - f0)
                     wf.append_iq_device(d_in.value + f0 * nfft * 8, nb, nfft, wait=False)
-                    if pending:
+                    wf.gather_begin(max_rows=nb, decimate=nfft // px, out=slots[i % 3])
+                    in_flight += 1
+                    if in_flight == 2:
                         got += wf.gather_end().shape[0]
-                    wf.gather_begin(max_rows=nb, decimate=nfft // px, out=slots[i & 1])
-                    pending = True
-                got += wf.gather_end().shape[0]
+                        in_flight -= 1
+                while in_flight:
+                    got += wf.gather_end().shape[0]
+                    in_flight -= 1
                 return got
 
             warm_up_by_time(run)
@@ -478,7 +482,7 @@ def channel_config5(lib, _ffi, pkg, SpectrumPlan, dev, n_frames=256, batch=24, p
             "pipelined": {"ms": round(_median(tp) * 1e3, 3), "ms_min": round(min(tp) * 1e3, 3), "ms_max": round(max(tp) * 1e3, 3),
                           "rows_gathered": rows_p, "Msamples_per_s": round(n_frames * nfft / _median(tp) / 1e6, 1),
                           "realtime_factor_at_61.44_Msps": round(n_frames * nfft / _median(tp) / 1e6 / 61.44, 1),
-                          "what": "append_iq_device(wait=False) + gather_begin / gather_end into pinned slots: batch i+1's "
+                          "what": "append_iq_device(wait=False) + gather_begin / gather_end into pinned slots, two read-outs in flight: batch i+1's "
                                   "transform is enqueued before batch i's rows are collected"}}
 
 
@@ -1062,13 +1066,16 @@ def main():
         launch_ms = kernel_ms / args.steps
         achieved = ALGO_BYTES_PER_SAMPLE * frames * NFFT / (launch_ms * 1e-3) / 1e9   # per GPU
         traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):                    # PMC-derived bytes per launch, see profiles/README.md
+        # PMC-derived bytes per launch from the newest round's collection (profiles/rNN/hbm_traffic.json, written by
+        # tools/install_profiles.py; see profiles/README.md)
+        import glob
+        rounds = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9]*", "hbm_traffic.json")))
+        if rounds:
             try:
-                rec = json.load(open(tpath))
+                rec = json.load(open(rounds[-1]))
                 if rec.get("frames") == frames and rec.get("window") == args.window:
                     traffic = rec.get("bytes_per_launch")
-                    traffic_src = ("profiles/hbm_traffic.json: a SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run "
+                    traffic_src = (f"{os.path.relpath(rounds[-1], REPO)}: a SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run "
                                    "of this command (not measured by this run)")
             except Exception:
                 traffic = None

@@ -380,8 +380,11 @@ int sdrk_waterfall_maxhold16_rows(const sdrk_waterfall* wf);
  * reduction behind everything appended so far and the device-to-host copy of its result on a second stream, and
  * returns; _end waits for that copy.  Between the two the caller can enqueue the next batch of frames
  * (sdrk_waterfall_append_iq_device_async), whose transform then runs while the previous batch's rows cross PCIe.
- * `out` must stay valid until _end (pinned memory makes the copy truly asynchronous).  One read in flight per
- * waterfall; n_rows is known at _begin. */
+ * `out` must stay valid until _end (pinned memory makes the copy truly asynchronous).  The reduction itself runs on that
+ * second stream too (behind an event), so the transform stream goes straight on; a later append waits for it only if it
+ * overwrites ring rows still being reduced.  Up to TWO reads may be in flight per waterfall — _end completes the OLDEST —
+ * so that a channel can enqueue batch i + 1 and begin its read-out before it collects batch i - 1 (the GPU then never
+ * waits for the host); a third _begin is refused.  n_rows is known at _begin. */
 int sdrk_waterfall_read_decimated_begin(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
                                         size_t* n_rows);
 int sdrk_waterfall_read_decimated_end(sdrk_waterfall* wf);

@@ -71,6 +71,9 @@ constexpr int FU_A = 256;                  // = M
 #else
 #define FU_T(slot) do { } while (0)
 #endif
+#ifndef FU_POLL_SLEEP
+#define FU_POLL_SLEEP 1                    // x 64 clocks between two polls that made no progress (2 / 4 / 8: within noise, r06)
+#endif
 constexpr int FU_RING_SLOTS = FU_RING_SLOTS_N;   // D; x 512 KiB per set, three sets per XCD
 constexpr int FU_MAX_XCD = 16;
 constexpr int FU_MAX_SETS = 64;            // dense set numbers (grid / 32 <= this)
@@ -120,7 +123,7 @@ __device__ __forceinline__ bool prog_spin(unsigned& spins, bool progressed, cons
         }
         return false;
     }
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(FU_POLL_SLEEP);
     return true;
 }
 

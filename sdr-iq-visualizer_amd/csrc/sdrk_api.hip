@@ -176,17 +176,20 @@ struct sdrk_waterfall {
     size_t head = 0;          // slot the next row is written to
     size_t count = 0;         // valid rows (<= maxlen)
     hipStream_t stream = nullptr;
-    void* d_dec = nullptr;    // decimated read-out staging (only grows)
-    size_t dec_cap = 0;
-    // two-phase decimated read-out: the reduction AND the copy run on a second stream behind the transform that produced the
-    // rows (ev_dec = "rows written", recorded on `stream`), so the transform stream goes straight on with the next batch;
-    // ev_dec_done = "reduction finished with the ring" (recorded on s_copy): a later write into ring slots [dec_start,
-    // dec_start + dec_rows) waits for it (wf_before_write) — in a running channel those are the newest rows and the next batch
-    // lands elsewhere, so nothing waits.
+    // decimated read-out staging (only grows).  Slot 0 also serves the one-call form (sdrk_waterfall_read_decimated).
+    void* d_dec[2] = {nullptr, nullptr};
+    size_t dec_cap[2] = {0, 0};
+    // two-phase decimated read-out, up to TWO in flight (a channel that enqueues batch i + 1 before it collects batch i - 1 keeps
+    // the transform stream fed): the reduction AND the copy run on a second stream behind the transform that produced the rows
+    // (ev_dec = "rows written", recorded on `stream`), so the transform stream goes straight on with the next batch;
+    // ev_dec_done[k] = "reduction k finished with the ring" (recorded on s_copy): a later write into ring slots [dec_start[k],
+    // dec_start[k] + dec_rows[k]) waits for it (wf_before_write) — in a running channel those are the newest rows and the next
+    // batch lands elsewhere, so nothing waits; ev_copy_done[k] = its rows are in the caller's array.
     hipStream_t s_copy = nullptr;
-    hipEvent_t ev_dec = nullptr, ev_dec_done = nullptr;
-    bool read_pending = false, dec_guard = false;
-    size_t dec_start = 0, dec_rows = 0;
+    hipEvent_t ev_dec = nullptr, ev_dec_done[2] = {nullptr, nullptr}, ev_copy_done[2] = {nullptr, nullptr};
+    int reads_in_flight = 0, oldest_read = 0;
+    bool dec_guard[2] = {false, false};
+    size_t dec_start[2] = {0, 0}, dec_rows[2] = {0, 0};
     // frame lengths whose transform can write them (sdrk::fft_tiled2_has_mip): every ring row max-hold-decimated by 16,
     // maxlen * nfft / 16 float32, written by the row pass beside the row itself; mip_ok[slot] = that slot's row came from
     // sdrk_waterfall_append_iq* (rows appended as finished rows have none)
@@ -1926,14 +1929,18 @@ int sdrk_waterfall_destroy(sdrk_waterfall* wf) {
         (void)hipStreamDestroy(wf->s_copy);
     }
     if (wf->ev_dec) (void)hipEventDestroy(wf->ev_dec);
-    if (wf->ev_dec_done) (void)hipEventDestroy(wf->ev_dec_done);
+    for (int k = 0; k < 2; ++k) {
+        if (wf->ev_dec_done[k]) (void)hipEventDestroy(wf->ev_dec_done[k]);
+        if (wf->ev_copy_done[k]) (void)hipEventDestroy(wf->ev_copy_done[k]);
+    }
     if (wf->stream) {
         (void)hipStreamSynchronize(wf->stream);
         (void)hipStreamDestroy(wf->stream);
     }
     if (wf->d_ring) (void)hipFree(wf->d_ring);
     if (wf->d_mip_ring) (void)hipFree(wf->d_mip_ring);
-    if (wf->d_dec) (void)hipFree(wf->d_dec);
+    for (int k = 0; k < 2; ++k)
+        if (wf->d_dec[k]) (void)hipFree(wf->d_dec[k]);
     delete wf;
     return SDRK_OK;
 }
@@ -1961,13 +1968,18 @@ int sdrk_waterfall_clear(sdrk_waterfall* wf) {
 // Before `run` ring slots from wf->head are overwritten on wf->stream: if the second stream's reduction may still be reading
 // any of them, the write waits for it.
 static hipError_t wf_before_write(sdrk_waterfall* wf, size_t run) {
-    if (!wf->dec_guard || run == 0) return hipSuccess;
+    if (run == 0) return hipSuccess;
     const size_t L = (size_t)wf->maxlen;
-    const size_t a0 = wf->head, b0 = wf->dec_start;           // both ranges may wrap: compare slot by modular distance
-    const bool overlap = ((b0 + L - a0) % L) < run || ((a0 + L - b0) % L) < wf->dec_rows;
-    if (!overlap) return hipSuccess;
-    wf->dec_guard = false;                                    // (a stream waits for an event once; later writes are behind it)
-    return hipStreamWaitEvent(wf->stream, wf->ev_dec_done, 0);
+    for (int k = 0; k < 2; ++k) {
+        if (!wf->dec_guard[k]) continue;
+        const size_t a0 = wf->head, b0 = wf->dec_start[k];    // both ranges may wrap: compare slot by modular distance
+        const bool overlap = ((b0 + L - a0) % L) < run || ((a0 + L - b0) % L) < wf->dec_rows[k];
+        if (!overlap) continue;
+        wf->dec_guard[k] = false;                             // (a stream waits for an event once; later writes are behind it)
+        const hipError_t e = hipStreamWaitEvent(wf->stream, wf->ev_dec_done[k], 0);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 static void wf_advance(sdrk_waterfall* wf, size_t rows) {
@@ -2083,16 +2095,17 @@ int sdrk_waterfall_read(sdrk_waterfall* wf, float* out, size_t max_rows, size_t*
     return SDRK_OK;
 }
 
-// the reduction of `rows` ring rows starting at slot `start` to nfft / factor bins each, into wf->d_dec: from the by-16
+// the reduction of `rows` ring rows starting at slot `start` to nfft / factor bins each, into wf->d_dec[slot]: from the by-16
 // rows when every requested slot has one (max mode, factor a multiple of 16) — 1/16 of the bytes —, else from the rows
-static hipError_t wf_launch_decimate(sdrk_waterfall* wf, size_t start, size_t rows, int factor, int mode, hipStream_t stream) {
+static hipError_t wf_launch_decimate(sdrk_waterfall* wf, size_t start, size_t rows, int factor, int mode, hipStream_t stream,
+                                     int slot) {
     bool mip = wf->d_mip_ring && mode == 0 && factor % 16 == 0;
     for (size_t r = 0; r < rows && mip; ++r) mip = wf->mip_ok[(start + r) % (size_t)wf->maxlen] != 0;
     if (mip)
         return sdrk::launch_decimate_mip(wf->d_mip_ring, wf->nfft, wf->maxlen, (int)start, (int)rows, factor,
-                                         static_cast<float*>(wf->d_dec), stream);
+                                         static_cast<float*>(wf->d_dec[slot]), stream);
     return sdrk::launch_decimate_rows(wf->d_ring, wf->nfft, wf->maxlen, (int)start, (int)rows, factor, mode,
-                                      static_cast<float*>(wf->d_dec), stream);
+                                      static_cast<float*>(wf->d_dec[slot]), stream);
 }
 
 int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_rows, int factor, int mode,
@@ -2101,7 +2114,7 @@ int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_row
     *n_rows = 0;
     if (factor < 1 || wf->nfft % factor != 0) return fail(SDRK_ERR_INVALID, "factor %d must divide nfft %d", factor, wf->nfft);
     if (mode != 0 && mode != 1) return fail(SDRK_ERR_INVALID, "mode must be 0 (max) or 1 (mean)");
-    if (wf->read_pending) return fail(SDRK_ERR_INVALID, "a two-phase decimated read is in flight (call _end first)");
+    if (wf->reads_in_flight) return fail(SDRK_ERR_INVALID, "a two-phase decimated read is in flight (call _end first)");
     size_t rows = wf->count < max_rows ? wf->count : max_rows;
     if (rows == 0) return SDRK_OK;
     if (!out) return fail(SDRK_ERR_INVALID, "out is NULL");
@@ -2109,11 +2122,11 @@ int sdrk_waterfall_read_decimated(sdrk_waterfall* wf, float* out, size_t max_row
     const size_t L = (size_t)wf->maxlen;
     const size_t start = (wf->head + L - rows % L) % L;
     const size_t bins = (size_t)(wf->nfft / factor);
-    int st = grow(wf->device, &wf->d_dec, &wf->dec_cap, rows * bins * sizeof(float));
+    int st = grow(wf->device, &wf->d_dec[0], &wf->dec_cap[0], rows * bins * sizeof(float));
     if (st != SDRK_OK) return st;
-    hipError_t e = wf_launch_decimate(wf, start, rows, factor, mode, wf->stream);
+    hipError_t e = wf_launch_decimate(wf, start, rows, factor, mode, wf->stream, 0);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "decimate launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(out, wf->d_dec, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->stream));
+    HIP_TRY(hipMemcpyAsync(out, wf->d_dec[0], rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->stream));
     HIP_TRY(hipStreamSynchronize(wf->stream));
     *n_rows = rows;
     return SDRK_OK;
@@ -2123,7 +2136,7 @@ int sdrk_waterfall_read_decimated_begin(sdrk_waterfall* wf, float* out, size_t m
                                         size_t* n_rows) {
     if (!wf || !n_rows) return fail(SDRK_ERR_INVALID, "waterfall or n_rows is NULL");
     *n_rows = 0;
-    if (wf->read_pending) return fail(SDRK_ERR_INVALID, "a decimated read is already in flight (call _end first)");
+    if (wf->reads_in_flight >= 2) return fail(SDRK_ERR_INVALID, "two decimated reads are already in flight (call _end first)");
     if (factor < 1 || wf->nfft % factor != 0) return fail(SDRK_ERR_INVALID, "factor %d must divide nfft %d", factor, wf->nfft);
     if (mode != 0 && mode != 1) return fail(SDRK_ERR_INVALID, "mode must be 0 (max) or 1 (mean)");
     size_t rows = wf->count < max_rows ? wf->count : max_rows;
@@ -2133,36 +2146,44 @@ int sdrk_waterfall_read_decimated_begin(sdrk_waterfall* wf, float* out, size_t m
     if (!wf->s_copy) {
         HIP_TRY(hipStreamCreateWithFlags(&wf->s_copy, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&wf->ev_dec, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&wf->ev_dec_done, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&wf->ev_dec_done[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&wf->ev_copy_done[k], hipEventDisableTiming));
+        }
     }
+    const int k = (wf->oldest_read + wf->reads_in_flight) & 1;
     const size_t L = (size_t)wf->maxlen;
     const size_t start = (wf->head + L - rows % L) % L;
     const size_t bins = (size_t)(wf->nfft / factor);
-    if (rows * bins * sizeof(float) > wf->dec_cap) HIP_TRY(hipStreamSynchronize(wf->s_copy));   // the staging is about to move
-    int st = grow(wf->device, &wf->d_dec, &wf->dec_cap, rows * bins * sizeof(float));
+    if (rows * bins * sizeof(float) > wf->dec_cap[k]) HIP_TRY(hipStreamSynchronize(wf->s_copy));   // the staging is about to move
+    int st = grow(wf->device, &wf->d_dec[k], &wf->dec_cap[k], rows * bins * sizeof(float));
     if (st != SDRK_OK) return st;
     // the rows are complete once everything enqueued on the transform stream so far has run; from there on the second stream
     HIP_TRY(hipEventRecord(wf->ev_dec, wf->stream));
     HIP_TRY(hipStreamWaitEvent(wf->s_copy, wf->ev_dec, 0));
-    hipError_t e = wf_launch_decimate(wf, start, rows, factor, mode, wf->s_copy);
+    hipError_t e = wf_launch_decimate(wf, start, rows, factor, mode, wf->s_copy, k);
     if (e != hipSuccess) return fail(SDRK_ERR_HIP, "decimate launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(wf->ev_dec_done, wf->s_copy));
-    wf->dec_start = start;
-    wf->dec_rows = rows;
-    wf->dec_guard = true;
-    HIP_TRY(hipMemcpyAsync(out, wf->d_dec, rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->s_copy));
-    wf->read_pending = true;
+    HIP_TRY(hipEventRecord(wf->ev_dec_done[k], wf->s_copy));
+    wf->dec_start[k] = start;
+    wf->dec_rows[k] = rows;
+    wf->dec_guard[k] = true;
+    HIP_TRY(hipMemcpyAsync(out, wf->d_dec[k], rows * bins * sizeof(float), hipMemcpyDeviceToHost, wf->s_copy));
+    HIP_TRY(hipEventRecord(wf->ev_copy_done[k], wf->s_copy));
+    ++wf->reads_in_flight;
     *n_rows = rows;
     return SDRK_OK;
 }
 
+// Waits for the OLDEST read in flight (its rows are then in the caller's array); no-op when none is.
 int sdrk_waterfall_read_decimated_end(sdrk_waterfall* wf) {
     if (!wf) return fail(SDRK_ERR_INVALID, "waterfall is NULL");
-    if (!wf->read_pending) return SDRK_OK;
+    if (!wf->reads_in_flight) return SDRK_OK;
     HIP_TRY(hipSetDevice(wf->device));
-    wf->read_pending = false;
-    wf->dec_guard = false;
-    HIP_TRY(hipStreamSynchronize(wf->s_copy));
+    const int k = wf->oldest_read;
+    wf->oldest_read ^= 1;
+    --wf->reads_in_flight;
+    wf->dec_guard[k] = false;                                  // (its copy is behind its reduction on the same stream)
+    HIP_TRY(hipEventSynchronize(wf->ev_copy_done[k]));
     return SDRK_OK;
 }
 

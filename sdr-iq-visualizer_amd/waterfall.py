@@ -39,7 +39,8 @@ class WaterfallBuffer:
         self.nfft, self.maxlen, self.device = nfft, maxlen, int(device)
         self._window, self._eps = window, float(eps)
         self._plan: Optional[SpectrumPlan] = None
-        self._gather: Optional[np.ndarray] = None     # the array a gather_begin() is filling (kept alive until gather_end())
+        # the arrays that gather_begin() calls are filling, oldest first (kept alive until their gather_end()); at most two
+        self._gather: Optional[list] = None
         self._lock = threading.Lock()
         self._handle = c_void_p()
         check(lib().sdrk_waterfall_create(self.device, nfft, maxlen, byref(self._handle)))
@@ -161,7 +162,9 @@ class WaterfallBuffer:
         """First half of a decimated read-out: the reduction is enqueued behind everything appended so far and its
         result starts crossing PCIe on a second stream; returns the (not yet filled) ``(rows, nfft // decimate)`` array.
         Call ``gather_end()`` before using it.  Between the two, ``append_iq_device(..., wait=False)`` of the next
-        batch overlaps this batch's copy.  ``out``: a float32 array (ideally ``pinned_empty``) with room for the rows."""
+        batch overlaps this batch's copy.  ``out``: a float32 array (ideally ``pinned_empty``) with room for the rows.
+        Up to TWO read-outs may be in flight (``gather_end()`` completes the oldest): a channel that enqueues batch i + 1 and
+        begins its read-out before it collects batch i - 1 never lets the transform stream run dry."""
         if mode not in ("max", "mean"):
             raise ValueError("mode must be 'max' or 'mean'")
         if decimate < 1 or self.nfft % decimate:
@@ -176,14 +179,19 @@ class WaterfallBuffer:
             got = c_size_t(0)
             check(lib().sdrk_waterfall_read_decimated_begin(self._h(), out.ctypes.data_as(c_void_p), c_size_t(rows),
                                                             int(decimate), 0 if mode == "max" else 1, byref(got)))
-            self._gather = out[: got.value]          # keeps the array alive until gather_end()
-            return self._gather
+            g = out[: got.value]
+            self._gather = (self._gather or []) + [g]      # keeps the array alive until its gather_end()
+            return g
 
     def gather_end(self) -> Optional[np.ndarray]:
-        """Second half: wait for the copy started by ``gather_begin`` and return its array."""
+        """Second half: wait for the copy started by the OLDEST ``gather_begin`` still in flight and return its array
+        (``None`` when nothing is in flight)."""
         with self._lock:
             check(lib().sdrk_waterfall_read_decimated_end(self._h()))
-            g, self._gather = self._gather, None
+            if not self._gather:
+                return None
+            g, rest = self._gather[0], self._gather[1:]
+            self._gather = rest or None
             return g
 
     def as_array(self, max_rows: Optional[int] = None, *, decimate: int = 1, mode: str = "max") -> np.ndarray:

@@ -151,10 +151,13 @@ static void waterfall_paths(int id) {
     void* d_x = nullptr;
     CHECK(sdrk_dev_alloc(0, x.size() * sizeof(c64), &d_x) == SDRK_OK && sdrk_memcpy_h2d(0, d_x, x.data(), x.size() * sizeof(c64)) == SDRK_OK);
     CHECK(sdrk_waterfall_append_iq_device_async(wf, p, static_cast<c64*>(d_x) + 7 * (size_t)nfft, 2, nfft) == SDRK_OK);           // frames 7, 8
+    std::vector<float> dec2(L * (size_t)(nfft / 16));
     CHECK(sdrk_waterfall_read_decimated_begin(wf, dec.data(), 2, 16, 0, &n) == SDRK_OK && n == 2);
-    CHECK(sdrk_waterfall_read_decimated_begin(wf, dec.data(), 2, 16, 0, &n) == SDRK_ERR_INVALID);                                 // one in flight
     CHECK(sdrk_waterfall_append_iq_device_async(wf, p, static_cast<c64*>(d_x) + 9 * (size_t)nfft, 3, nfft) == SDRK_OK);           // frames 9..11 meanwhile
-    CHECK(sdrk_waterfall_read_decimated_end(wf) == SDRK_OK);
+    CHECK(sdrk_waterfall_read_decimated_begin(wf, dec2.data(), 3, 16, 0, &n) == SDRK_OK && n == 3);                               // a second one in flight
+    CHECK(sdrk_waterfall_read_decimated_begin(wf, dec2.data(), 3, 16, 0, &n) == SDRK_ERR_INVALID);                                // ... a third is refused
+    CHECK(sdrk_waterfall_read_decimated(wf, dec2.data(), 1, 16, 0, &n) == SDRK_ERR_INVALID);                                      // and so is the one-call form
+    CHECK(sdrk_waterfall_read_decimated_end(wf) == SDRK_OK);                                                                      // the OLDEST: frames 7, 8
     size_t wrong = 0;
     for (int r = 0; r < 2; ++r)
         for (int b = 0; b < nfft / 16; ++b) {
@@ -163,6 +166,15 @@ static void waterfall_paths(int id) {
             wrong += dec[(size_t)r * (nfft / 16) + b] != mx;
         }
     CHECK(wrong == 0);
+    CHECK(sdrk_waterfall_read_decimated_end(wf) == SDRK_OK);                                                                      // then frames 9..11
+    for (int r = 0; r < 3; ++r)
+        for (int b = 0; b < nfft / 16; ++b) {
+            float mx = -INFINITY;
+            for (int i = 0; i < 16; ++i) mx = std::fmax(mx, ref[(size_t)(9 + r) * nfft + (size_t)b * 16 + i]);
+            wrong += dec2[(size_t)r * (nfft / 16) + b] != mx;
+        }
+    CHECK(wrong == 0);
+    CHECK(sdrk_waterfall_read_decimated_end(wf) == SDRK_OK);                                                                      // none left: no-op
     CHECK(sdrk_waterfall_sync(wf, p) == SDRK_OK);
     CHECK(sdrk_waterfall_read(wf, got.data(), L, &n) == SDRK_OK && n == (size_t)L);
     CHECK(memcmp(got.data(), ref.data() + 7 * (size_t)nfft, L * (size_t)nfft * 4) == 0);                                          // frames 7..11

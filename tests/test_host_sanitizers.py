@@ -264,7 +264,7 @@ def test_waterfall_close_is_serialised_with_calls_in_flight(monkeypatch):
     monkeypatch.setattr(w, "lib", lambda: fake)
     monkeypatch.setattr(w._ffi, "require_device", lambda d: None)
     wf = w.WaterfallBuffer(8, maxlen=4)
-    assert wf._gather is None                                   # initialised in __init__, not on first use
+    assert wf._gather is None                                   # initialised in __init__, not on first use (None: nothing in flight)
     t = threading.Thread(target=lambda: wf.append_rows(np.zeros(8, np.float32)))
     t.start()
     while "append begins" not in events:

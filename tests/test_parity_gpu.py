@@ -1116,14 +1116,31 @@ def test_waterfall_async_append_and_two_phase_gather(pkg):
                 wf.gather_begin(max_rows=batch, decimate=f, out=np.empty((1, 3), np.float32))
             wf.gather_begin(max_rows=batch, decimate=f, out=slots[b & 1])
             pending = True
-            with pytest.raises(ValueError):                       # one read in flight per waterfall
-                wf.gather_begin(max_rows=batch, decimate=f)
             with pytest.raises(ValueError):
-                wf.as_array(decimate=f)
+                wf.as_array(decimate=f)                           # the one-call form shares the staging: refused meanwhile
         got.append(wf.gather_end().copy())
         assert wf.gather_end() is None                           # nothing in flight any more
         for b in range(nb):
             assert np.array_equal(got[b], blocking[b]), b
+        # two read-outs in flight (the deeper pipeline of bench.py's channel leg): batch b + 1 is appended and its read-out begun
+        # before batch b - 1 is collected; a third begin is refused; gather_end() hands the arrays back oldest first.  The ring
+        # holds 7 rows and a batch 3: the append of batch b + 2 overwrites rows whose reduction may still be running — the
+        # write has to wait for it (wf_before_write), or batch b's rows would come back wrong.
+        wf.clear()
+        slots3 = [pkg.pinned_empty((batch, n // f), np.float32) for _ in range(3)]
+        got2 = []
+        for b in range(nb):
+            wf.append_iq_device(d_in.value + b * batch * n * 8, batch, wait=False)
+            wf.gather_begin(max_rows=batch, decimate=f, out=slots3[b % 3])
+            if b == 1:
+                with pytest.raises(ValueError):                   # two in flight: a third is refused
+                    wf.gather_begin(max_rows=batch, decimate=f)
+            if b >= 1:
+                got2.append(wf.gather_end().copy())               # the OLDEST: batch b - 1
+        got2.append(wf.gather_end().copy())
+        assert wf.gather_end() is None
+        for b in range(nb):
+            assert np.array_equal(got2[b], blocking[b]), ("two in flight", b)
         wf.sync()
         assert len(wf) == 7
         assert_db_parity(wf.as_array(), cpu_ref.spectrum_db(x[-7:], window=np.hanning(n)), what="ring after async appends")

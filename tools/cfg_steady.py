@@ -30,6 +30,9 @@ ap.add_argument("--transforms", type=int, default=20)
 ap.add_argument("--isolated", action="store_true")
 ap.add_argument("--idle-ms", type=float, default=0.0, help="sleep this long between the warm-up and the timed transforms")
 ap.add_argument("--out", default=None)
+ap.add_argument("--form", choices=["default", "tiled", "fused"], default="default",
+                help="nfft = 65536 only: the plan's default (the persistent launch from 512 frames), the two tiled launches, or "
+                     "the persistent launch for every call")
 a = ap.parse_args()
 
 from bench import Telemetry  # noqa: E402  (the sampler only; nothing of the bench runs)
@@ -49,7 +52,8 @@ tel = Telemetry(_ffi.device_info(dev))
 rec = {"nfft": a.nfft, "frames": a.frames, "hop": a.hop, "window": a.window, "isolated": a.isolated,
        "library": _ffi.library_path(), "profiled": bool(os.environ.get("ROCPROFILER_LIBRARY_CTOR") or os.environ.get("ROCP_TOOL_LIBRARIES")
                                                       or "rocprof" in os.environ.get("LD_PRELOAD", ""))}
-with SpectrumPlan(a.nfft, window=window, device=dev) as plan:
+rec["form"] = a.form
+with SpectrumPlan(a.nfft, window=window, device=dev, fused64k={"default": None, "tiled": False, "fused": True}[a.form]) as plan:
     warm = []
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < a.warm_ms or len(warm) < 3:

@@ -3,9 +3,9 @@
 #   tools/collect_round.sh r02
 # -> gpurun_out/collect_<tag>/ : rocprofv3 evidence (tools/profile_round.sh), the bench line, the size sweep,
 #    the placement probes and N bench processes with and without placement tuning.
-# SDRK_COLLECT_LIGHT=1: what changed or is quoted this round only — skips the placement micro-probes, the fused-vs-tiled and
-# overlap A/B runs (closed experiments: their logs of the round that ran them stand) and halves the bench-process counts.
-TAG=${1:-r05}
+# SDRK_COLLECT_LIGHT=1: what changed or is quoted this round only — skips the placement micro-probes and the overlap A/B
+# runs (closed experiments: their logs of the round that ran them stand) and halves the bench-process counts.
+TAG=${1:-r06}
 LIGHT=${SDRK_COLLECT_LIGHT:-0}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/collect_$TAG
@@ -17,8 +17,8 @@ PART=${SDRK_COLLECT_PART:-AB}
 case $PART in *A*)
 echo "== bench (full line)"; python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "== profiles"; bash tools/profile_round.sh $TAG > "$OUT/profile_round.log" 2>&1; cp gpurun_out/prof_$TAG/summary.json "$OUT/rocprof_summary.json"; cp gpurun_out/prof_$TAG/pmc_fetch_write_rows.csv "$OUT/" 2>/dev/null
-for t in bench cfg3 cfg5 n16384 n2p21 n2p22 feat; do cp gpurun_out/prof_$TAG/${t}_trace/*/*kernel_stats.csv "$OUT/${t}_kernel_stats.csv" 2>/dev/null; done
-cp gpurun_out/prof_$TAG/cfg3_trace_vs_events.json gpurun_out/prof_$TAG/cfg5_trace_vs_events.json gpurun_out/prof_$TAG/cfg3_steady.json gpurun_out/prof_$TAG/cfg5_steady.json "$OUT/" 2>/dev/null
+for t in bench cfg3 cfg3tiled cfg5 n16384 n2p21 n2p22 feat; do cp gpurun_out/prof_$TAG/${t}_trace/*/*kernel_stats.csv "$OUT/${t}_kernel_stats.csv" 2>/dev/null; done
+cp gpurun_out/prof_$TAG/cfg3_trace_vs_events.json gpurun_out/prof_$TAG/cfg3tiled_trace_vs_events.json gpurun_out/prof_$TAG/cfg5_trace_vs_events.json gpurun_out/prof_$TAG/cfg3_steady.json gpurun_out/prof_$TAG/cfg3tiled_steady.json gpurun_out/prof_$TAG/cfg5_steady.json "$OUT/" 2>/dev/null
 echo "== the continuous channel (config 5 as worded), kernel-traced"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/channel_trace" -- python3 "$ROOT/tools/channel_probe.py" --batch 24 > "$OUT/channel_probe.json" 2> /dev/null )
 python3 tools/summarise_channel_trace.py "$OUT/channel_trace" --batches 11 --runs 6 > "$OUT/channel_trace_summary.json" 2>/dev/null; cp "$OUT"/channel_trace/*/*kernel_stats.csv "$OUT/channel_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/channel_trace"
@@ -42,10 +42,11 @@ print('%.4f  %.4f  %.4f  %.4f  %7.1f  %.4f  sclk_after %s  probe_ms %s chosen %d
   for i in $(seq $NP); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 2>/dev/null | tail -1 | summ; done; } > "$OUT/placement_runs.txt"
 { echo "# the same with --placement-candidates 1 (plain alloc(in); alloc(out)), $NQ processes";
   for i in $(seq $NQ); do python3 bench.py --no-secondary --cpu-seconds 0 --parity-frames 0 --placement-candidates 1 2>/dev/null | tail -1 | summ; done; } > "$OUT/plain_alloc_runs.txt"
-if [ "$LIGHT" != 1 ]; then
-echo "== fused vs tiled N=65536 (4096 packed frames, then config 3; Hann)"
+echo "== N=65536: the persistent launch against the two tiled launches (4096 packed frames, then config 3; Hann), and their crossover"
 { python3 tools/fused_probe.py 4096 65536 hann; python3 tools/fused_probe.py 18749 32768 hann; } > "$OUT/fused64k_vs_tiled.log" 2>&1
+{ python3 experiments/fused64k_policy/crossover.py 32768; python3 experiments/fused64k_policy/crossover.py 65536; } > "$OUT/fused64k_crossover.log" 2>&1
 cat "$OUT/fused64k_vs_tiled.log"; tail -3 "$OUT/placement_runs.txt"; tail -3 "$OUT/plain_alloc_runs.txt"
+if [ "$LIGHT" != 1 ]; then
 echo "== overlap of the two large-frame passes (SDRK_PLAN_OVERLAP_PASSES): sweep, then kernel traces"
 timeout -k 10 400 python3 tools/overlap_probe.py both > "$OUT/overlap_probe.log" 2>&1; tail -4 "$OUT/overlap_probe.log"
 ( cd /tmp && export TMPDIR=/tmp
@@ -82,5 +83,9 @@ echo "== bench.py --gpus 2, self-launched (rehearsal on one GPU: gloo rendezvous
 python3 bench.py --gpus 2 --steps 3 --warmup 1 --frames 262144 --cpu-seconds 3 --cpu-all-cores-seconds 2 2> "$OUT/bench_gpus2_rehearsal.err" | grep '^{' > "$OUT/bench_gpus2_rehearsal.json"; echo "rc=$? $(wc -c < "$OUT/bench_gpus2_rehearsal.json") bytes"
 echo "== bench.py --gpus 4, self-launched on the one GPU (the control path of configs[3] / [4]; the -m gpu suite runs the same)"
 python3 bench.py --gpus 4 --steps 3 --warmup 1 --frames 65536 --first-frame 3145728 --cpu-seconds 0 --placement-candidates 1 2> "$OUT/bench_gpus4_rehearsal.err" | grep '^{' > "$OUT/bench_gpus4_rehearsal.json"; echo "rc=$? $(wc -c < "$OUT/bench_gpus4_rehearsal.json") bytes"
+echo "== bench.py --gpus 5, self-launched on the one GPU: the most ranks this pool's process guard admits beside the launcher (6 processes on"
+echo "   the card; a 6-rank rehearsal was killed by it in round 6: profiles/r06/bench_gpus7_refused.txt).  frames 4096 per rank as the driver's"
+echo "   8-GPU command line would be rehearsed; first frame 3 x 2^20 so that every rank's samples lie past index 2^32"
+python3 bench.py --gpus 5 --frames 4096 --first-frame 3145728 --steps 3 --warmup 1 --cpu-seconds 0 --placement-candidates 1 2> "$OUT/bench_gpus5_rehearsal.err" | grep '^{' > "$OUT/bench_gpus5_rehearsal.json"; echo "rc=$? $(wc -c < "$OUT/bench_gpus5_rehearsal.json") bytes"
 echo "== one-frame host call"; python3 tools/small_call_probe.py > "$OUT/small_call_probe.log" 2>&1; cat "$OUT/small_call_probe.log"
 echo "== gpu tests"; python3 -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -2 "$OUT/pytest_gpu.log"

@@ -5,7 +5,7 @@
 # MI355X guide prescribes) of the bench and of BASELINE configs 3 and 5.  Outputs under gpurun_out/prof_<tag>/;
 # tools/summarise_profiles.py turns them into the files committed under profiles/<tag>/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 LIGHT=${SDRK_COLLECT_LIGHT:-0}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -33,6 +33,11 @@ for cfg in "${CFGS[@]}"; do
     run $1_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/$1_fetch" -- python3 "$ROOT/tools/cfg_steady.py" $2 $3 $4 $5 --transforms 4 --warm-ms 40
     run $1_write --pmc WRITE_SIZE --output-format csv -d "$OUT/$1_write" -- python3 "$ROOT/tools/cfg_steady.py" $2 $3 $4 $5 --transforms 4 --warm-ms 40
 done
+# BASELINE config 3 in its other form, the two tiled launches (the default plan above takes the one persistent launch since round 6)
+run cfg3tiled_trace --kernel-trace --stats --output-format csv -d "$OUT/cfg3tiled_trace" -- python3 "$ROOT/tools/cfg_steady.py" 65536 18749 32768 hann --form tiled --transforms 12 --out "$OUT/cfg3tiled_steady.json"
+python3 "$ROOT/tools/summarise_cfg_trace.py" "$OUT/cfg3tiled_trace" "$OUT/cfg3tiled_steady.json" > "$OUT/cfg3tiled_trace_vs_events.json" 2>> "$OUT/summary.err"
+run cfg3tiled_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/cfg3tiled_fetch" -- python3 "$ROOT/tools/cfg_steady.py" 65536 18749 32768 hann --form tiled --transforms 4 --warm-ms 40
+run cfg3tiled_write --pmc WRITE_SIZE --output-format csv -d "$OUT/cfg3tiled_write" -- python3 "$ROOT/tools/cfg_steady.py" 65536 18749 32768 hann --form tiled --transforms 4 --warm-ms 40
 # the per-row reductions: kernel trace + SQ instruction / activity counters, separate passes
 run feat_trace --kernel-trace --stats --output-format csv -d "$OUT/feat_trace" -- python3 "$ROOT/tools/feat_probe.py"
 run feat_sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d "$OUT/feat_sq1" -- python3 "$ROOT/tools/feat_probe.py"

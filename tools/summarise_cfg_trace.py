@@ -25,7 +25,7 @@ rows = []
 for r in csv.DictReader(open(f)):
     m = re.search(r"sdrk::(\w+)(<[^>]*>)?", r["Kernel_Name"])
     name = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:40]
-    if "col_pass" in name or "row_pass" in name:
+    if "col_pass" in name or "row_pass" in name or "fused64k" in name:     # (N = 65536, default plan: ONE persistent launch)
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 # launches per transform: from the run of the first kernel name repeating
@@ -46,8 +46,12 @@ for t in range(K):
     out["row_us"].append(round(row, 1))
     out["kernel_sum_ms"].append(round((col + row) / 1e3, 4))
     out["span_ms"].append(round(span / 1e3, 4))
-    out["idle_inside_span_us"].append(round(span - col - row, 1))
-chunks = per // 2
+    fused = sum(e - s for s, e, n in ks if "fused64k" in n) / 1e3
+    if fused:
+        out.setdefault("fused_us", []).append(round(fused, 1))
+        out["kernel_sum_ms"][-1] = round((col + row + fused) / 1e3, 4)
+    out["idle_inside_span_us"].append(round(span - col - row - fused, 1))
+chunks = max(per // 2, 1)
 out["median"] = {"col_us_per_launch": round(statistics.median(out["col_us"]) / chunks, 2),
                  "row_us_per_launch": round(statistics.median(out["row_us"]) / chunks, 2),
                  "kernel_sum_ms": statistics.median(out["kernel_sum_ms"]), "span_ms": statistics.median(out["span_ms"])}
