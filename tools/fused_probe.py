@@ -1,8 +1,9 @@
 """Developer helper (GPU box): N = 65536, the fused single-launch kernel against the two tiled launches.
     python tools/fused_probe.py [frames] [hop] [window]
-Prints the median of 7 timed executions of each and the largest difference between their outputs."""
+Prints the median of 7 timed executions of each (after 100 ms of warm-up) and the largest difference between their outputs."""
 import ctypes
 import sys
+import time
 
 import numpy as np
 
@@ -24,9 +25,11 @@ _ffi.check(lib.sdrk_synth_fill(0, 3, 0, (samples + 4095) // 4096, 4096, d_in, No
 res = {}
 for name, kw, d_out in (("tiled", {"fused64k": False}, d_a), ("fused", {"fused64k": True}, d_b)):
     with SpectrumPlan(n, window=None if window == "rect" else window, **kw) as p:
-        p.exec_device(d_in.value, nf, d_out.value, frame_stride=hop)
-        p.sync()
+        t0 = time.perf_counter()                     # warm up BY TIME (an idle device needs tens of ms to reach its clock)
+        while time.perf_counter() - t0 < 0.1:
+            p.exec_device_timed(d_in.value, nf, d_out.value, 1, frame_stride=hop)
         ms = sorted(p.exec_device_timed_each(d_in.value, nf, d_out.value, 7, frame_stride=hop))
+        p.sync()
         alg = (8 * samples + 4 * nf * n) / ms[3] / 1e6
         print(f"{name}: median {ms[3]:.3f} ms (min {ms[0]:.3f}) for {nf} frames hop {hop}: {alg:.0f} GB/s algorithmic, "
               f"{alg / 8000:.3f} of peak")
