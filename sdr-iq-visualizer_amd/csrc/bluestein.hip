@@ -15,13 +15,15 @@
 
 namespace sdrk {
 
+// L = M: whole zero-padded frames; L = N (compact): only the values that exist, at stride M
 __global__ __launch_bounds__(256) void blu_pre_kernel(const float2* __restrict__ iq, size_t frame_stride,
-                                                      size_t n_frames, int N, int M, const float* __restrict__ window,
+                                                      size_t n_frames, int N, int M, int L, const float* __restrict__ window,
                                                       const float2* __restrict__ chirp, float2* __restrict__ a) {
-    const size_t total = n_frames * (size_t)M;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t f = i / M;
-        const int m = (int)(i - f * M);
+    const size_t total = n_frames * (size_t)L;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += (size_t)gridDim.x * 256) {
+        const size_t f = i0 / L;
+        const int m = (int)(i0 - f * L);
+        const size_t i = f * (size_t)M + m;
         float2 v = make_float2(0.f, 0.f);
         if (m < N) {
             float2 x = iq[f * frame_stride + m];
@@ -202,13 +204,13 @@ static unsigned blu_grid(size_t total, int num_cus) {
 }
 
 hipError_t launch_blu_pre(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
-                          const void* d_chirp, void* d_a, int num_cus, hipStream_t s) {
-    hipLaunchKernelGGL(blu_pre_kernel, dim3(blu_grid(n_frames * (size_t)M, num_cus)), dim3(256), 0, s,
-                       static_cast<const float2*>(d_iq), frame_stride, n_frames, N, M, d_window,
+                          const void* d_chirp, void* d_a, int num_cus, hipStream_t s, bool compact) {
+    const int L = compact ? N : M;
+    hipLaunchKernelGGL(blu_pre_kernel, dim3(blu_grid(n_frames * (size_t)L, num_cus)), dim3(256), 0, s,
+                       static_cast<const float2*>(d_iq), frame_stride, n_frames, N, M, L, d_window,
                        static_cast<const float2*>(d_chirp), static_cast<float2*>(d_a));
     return hipGetLastError();
 }
-
 hipError_t launch_blu_mul(const void* d_A, const void* d_B, size_t n_frames, int M, void* d_out, int num_cus,
                           hipStream_t s) {
     hipLaunchKernelGGL(blu_mul_kernel, dim3(blu_grid(n_frames * (size_t)M, num_cus)), dim3(256), 0, s,

@@ -66,7 +66,7 @@ template <int LOG2A, bool HAS_WINDOW, int W, bool FIXED, int SH>
 __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 ? 4 : 3)) void col_pass_kernel(
     const float2* __restrict__ iq, size_t frame_stride, float2* __restrict__ scratch, size_t n_frames, int M,
     const float* __restrict__ window, const float2* __restrict__ twA, const float2* __restrict__ t1T,
-    const float2* __restrict__ t2) {
+    const float2* __restrict__ t2, unsigned in_bytes) {   // in_bytes: bytes of each input frame that exist (the rest reads as zeros)
     using C = LdsCfg<LOG2A>;
     constexpr int A = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 17/16 A W elements: W interleaved columns
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
         int m = 0;
         const bool live = g < items;
         if (live) locate(g, f, m);
-        const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + f * frame_stride, live ? (unsigned)(nfft * 8) : 0u);
+        const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + f * frame_stride, live ? in_bytes : 0u);
         const int e0 = tau * M + m;          // element (n3 = tau, m)
 #pragma unroll
         for (int q = 0; q < 16; ++q)
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, (LdsCfg<LOG2A>::T * W >= 512 
         // loads q >= q0 of frame f (zero-sized descriptor past the run: zeros, no memory access)
         auto issue_from = [&](size_t f, v2f (&x)[16], int q0) {
             const bool live = f < f_end;
-            const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + (live ? f : f_begin) * frame_stride, live ? (unsigned)(nfft * 8) : 0u);
+            const __amdgpu_buffer_rsrc_t rx = frame_rsrc(iq + (live ? f : f_begin) * frame_stride, live ? in_bytes : 0u);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 if (q >= q0) x[q] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, e0 * 8, q * estep * 8, SDRK_COL_LD_AUX));
@@ -232,7 +232,7 @@ template <int LOG2A, bool HAS_WINDOW, int W>
 __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kernel(
     const float2* __restrict__ iq, size_t frame_stride, float2* __restrict__ scratch, size_t n_frames, int M,
     const float* __restrict__ window, const float2* __restrict__ twA, const float2* __restrict__ t1T,
-    const float2* __restrict__ t2) {
+    const float2* __restrict__ t2, unsigned in_bytes) {
     using C = LdsCfg<LOG2A>;
     constexpr int A = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0;
     constexpr int LPR = W / 2;                                            // lanes per row: 16 bytes each
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2A>::T * W, 2) void col_pass_staged_kerne
         auto dma = [&](size_t f) {
             if (f >= f_end) return;                  // nothing may still be writing LDS when the workgroup exits
             const unsigned long long base = (unsigned long long)(iq + f * frame_stride);
-            const v4u32 rx = {(unsigned)base, (unsigned)(base >> 32) & 0xffffu, (unsigned)(nfft * 8), 0x00020000u};
+            const v4u32 rx = {(unsigned)base, (unsigned)(base >> 32) & 0xffffu, in_bytes, 0x00020000u};
 #pragma unroll
             for (int i = 0; i < INSTR; ++i) {
                 const int grp = wave + WAVES * i;                          // rows ROWS_PER_INSTR * grp ...
@@ -352,10 +352,40 @@ __host__ __device__ constexpr int staged_per_cu(int SLOT, int A, int W) {
 
 // row pass for M = 256 and 512: tile = 16 adjacent k3 rows x M (34.8 / 69.6 KiB of LDS: four / two workgroups per
 // CU, which overlap each other's load, transform and store phases).
+// The complex epilogues of the row passes: plain (EPI_COMPLEX) or with the chirp-z multiplies riding on the stores.
+//   k = natural output index A km + k3 of the value (the EPI_BLU_* forms run unshifted), f = frame, nfft = A M.
+struct EpiTab {
+    const float2* tab;   // EPI_BLU_MUL: filter spectrum [nfft]; EPI_BLU_POST_*: chirp [n_out]
+    int n_out;           // EPI_BLU_POST_*: values per output row
+    int rot;             //                 fftshift rotation (n_out / 2 or 0)
+    float inv_m;         //                 1 / nfft
+};
+template <int EPILOGUE>
+__device__ __forceinline__ void epi_store_complex(void* __restrict__ out_raw, size_t f, size_t nfft, size_t k, float2 v,
+                                                  const EpiTab& t, float eps) {
+    if (EPILOGUE == EPI_COMPLEX) {
+        static_cast<float2*>(out_raw)[f * nfft + k] = v;
+    } else if (EPILOGUE == EPI_BLU_MUL) {
+        const float2 b = t.tab[k];
+        static_cast<float2*>(out_raw)[f * nfft + k] = make_float2(fmaf(v.x, b.x, -(v.y * b.y)), -fmaf(v.x, b.y, v.y * b.x));  // conj(v b)
+    } else {
+        if (k >= (size_t)t.n_out) return;
+        const float2 c = t.tab[k];
+        const float re = fmaf(c.x, v.x, -(c.y * v.y)) * t.inv_m;                   // conj(c v) / M, as blu_post_kernel forms it
+        const float im = -fmaf(c.x, v.y, c.y * v.x) * t.inv_m;
+        size_t dst = k + (size_t)t.rot;
+        if (dst >= (size_t)t.n_out) dst -= (size_t)t.n_out;
+        if (EPILOGUE == EPI_BLU_POST_LOG)
+            static_cast<float*>(out_raw)[f * (size_t)t.n_out + dst] = logpsd_db(re, im, eps);
+        else
+            static_cast<float2*>(out_raw)[f * (size_t)t.n_out + dst] = make_float2(re, im);
+    }
+}
+
 template <int LOG2M, int EPILOGUE>
 __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 512 ? 4 : 3)) void row_pass_kernel(
     const float2* __restrict__ scratch, void* __restrict__ out_raw, size_t n_frames, int A,
-    const float2* __restrict__ twM, float eps, int shift) {
+    const float2* __restrict__ twM, float eps, int shift, EpiTab epi) {
     using C = LdsCfg<LOG2M>;
     constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, ROWS = 16;
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];  // 16 rows x SLOT, reused for the transpose
@@ -409,14 +439,22 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 51
                 tile[(rt + T * (q ^ xor_q)) * (ROWS + 1) + fr] = make_float2(z.x, z.y);
             }
             __syncthreads();
-            // (buffer stores like the log branch: sixteen unrolled 64-bit addresses cost this branch its fourth wave per SIMD)
-            const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float2*>(out_raw) + f * nfft + k3_0,
-                                                         (unsigned)((nfft - k3_0) * 8));
             const int r = tid & (ROWS - 1), km0 = tid / ROWS;
+            if (EPILOGUE == EPI_COMPLEX) {
+                // (buffer stores like the log branch: sixteen unrolled 64-bit addresses cost this branch its fourth wave per SIMD)
+                const __amdgpu_buffer_rsrc_t ro = frame_rsrc(static_cast<float2*>(out_raw) + f * nfft + k3_0,
+                                                             (unsigned)((nfft - k3_0) * 8));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float2 val = tile[(km0 + T * i) * (ROWS + 1) + r];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, val), ro, (km0 * A + r) * 8, i * T * A * 8, 0);
+                for (int i = 0; i < 16; ++i) {
+                    const float2 val = tile[(km0 + T * i) * (ROWS + 1) + r];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, val), ro, (km0 * A + r) * 8, i * T * A * 8, 0);
+                }
+            } else {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const float2 val = tile[(km0 + T * i) * (ROWS + 1) + r];
+                    epi_store_complex<EPILOGUE>(out_raw, f, nfft, (size_t)(km0 + T * i) * A + k3_0 + r, val, epi, eps);
+                }
             }
         }
         __syncthreads();  // tile reads done before the next item's exchanges
@@ -436,7 +474,7 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 16, (LdsCfg<LOG2M>::T * 16 >= 51
 template <int LOG2M, int EPILOGUE>
 __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
     const float2* __restrict__ scratch, void* __restrict__ out_raw, size_t n_frames, int A,
-    const float2* __restrict__ twM, float eps, int shift) {
+    const float2* __restrict__ twM, float eps, int shift, EpiTab epi) {
     using C = LdsCfg<LOG2M>;
     constexpr int M = C::N, R0 = C::R0, T = C::T, C0 = 16 / R0, WGT = T * 8;
     static_assert((size_t)M * 17 * sizeof(float) <= (size_t)8 * C::SLOT * sizeof(float2), "transpose tile must fit the exchange area");
@@ -488,12 +526,21 @@ __global__ __launch_bounds__(LdsCfg<LOG2M>::T * 8, 4) void row_pass_pair_kernel(
                     tile[(rt + T * (q ^ xor_q)) * 9 + fr] = make_float2(z.x, z.y);
                 }
                 __syncthreads();
-                float2* __restrict__ o = static_cast<float2*>(out_raw) + f * nfft + k3_0 + 8 * h;
+                if (EPILOGUE == EPI_COMPLEX) {
+                    float2* __restrict__ o = static_cast<float2*>(out_raw) + f * nfft + k3_0 + 8 * h;
 #pragma unroll 8
-                for (int i = 0; i < 8 * M / WGT; ++i) {
-                    const int e = tid + WGT * i;
-                    const int r = e & 7, km = e >> 3;
-                    o[(size_t)km * A + r] = tile[km * 9 + r];
+                    for (int i = 0; i < 8 * M / WGT; ++i) {
+                        const int e = tid + WGT * i;
+                        const int r = e & 7, km = e >> 3;
+                        o[(size_t)km * A + r] = tile[km * 9 + r];
+                    }
+                } else {
+#pragma unroll 4
+                    for (int i = 0; i < 8 * M / WGT; ++i) {
+                        const int e = tid + WGT * i;
+                        const int r = e & 7, km = e >> 3;
+                        epi_store_complex<EPILOGUE>(out_raw, f, nfft, (size_t)km * A + k3_0 + 8 * h + r, tile[km * 9 + r], epi, eps);
+                    }
                 }
                 __syncthreads();  // tile reads done before the next half's exchanges
             }
@@ -688,6 +735,9 @@ bool fft_tiled2_split(int nfft, int* log2a, int* log2m) {
 }
 
 // col pass through col_pass_staged_kernel: one 512-thread workgroup per CU (133.5 KiB of LDS)
+// bytes of each input frame that exist (LaunchArgs::in_valid; the whole frame by default)
+static unsigned col_in_bytes(const LaunchArgs& a) { return (unsigned)((a.in_valid ? a.in_valid : (size_t)a.nfft) * 8); }
+
 template <int LOG2A, int W>
 static hipError_t launch_col_staged(const LaunchArgs& a, const float2* src, size_t nf, int M) {
     using C = LdsCfg<LOG2A>;
@@ -706,7 +756,7 @@ static hipError_t launch_col_staged(const LaunchArgs& a, const float2* src, size
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
         if (e0 != hipSuccess) return e0;                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * W), lds_bytes, a.stream, src, a.frame_stride, scratch, nf, M, \
-                           a.d_window, twA, t1T, t2);                                                            \
+                           a.d_window, twA, t1T, t2, col_in_bytes(a));                                           \
     } while (0)
     if (a.d_window) SDRK_COLS(true); else SDRK_COLS(false);
 #undef SDRK_COLS
@@ -750,7 +800,7 @@ static hipError_t launch_col_tiles(const LaunchArgs& a, const float2* src, size_
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
         if (e0 != hipSuccess) return e0;                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * W), lds_bytes, a.stream, src, a.frame_stride, scratch, nf, \
-                           M, a.d_window, twA, t1T, t2);                                                            \
+                           M, a.d_window, twA, t1T, t2, col_in_bytes(a));                                           \
     } while (0)
     if (CAN_FIX && fixed) {
         if (sh == 8) { if (a.d_window) SDRK_COL(true, CAN_FIX, (CAN_FIX ? 8 : 16)); else SDRK_COL(false, CAN_FIX, (CAN_FIX ? 8 : 16)); }
@@ -771,6 +821,18 @@ static hipError_t launch_col(const LaunchArgs& a, const float2* src, size_t nf, 
 
 
 // row pass through row_pass_pair_kernel (M >= 1024): as many workgroups per CU as their LDS allows
+static EpiTab epi_tab(const LaunchArgs& a) {
+    EpiTab t;
+    t.tab = a.d_epi_tab;
+    t.n_out = a.epi_n_out;
+    t.rot = a.shift ? a.epi_n_out / 2 : 0;
+    t.inv_m = 1.0f / (float)a.nfft;
+    return t;
+}
+// element size and frame stride (in elements) of a row pass's output, by epilogue
+static size_t out_elem_bytes(const LaunchArgs& a) { return (a.epilogue == EPI_LOGPSD || a.epilogue == EPI_BLU_POST_LOG) ? sizeof(float) : sizeof(float2); }
+static size_t out_row_elems(const LaunchArgs& a) { return (a.epilogue == EPI_BLU_POST_LOG || a.epilogue == EPI_BLU_POST_C64) ? (size_t)a.epi_n_out : (size_t)a.nfft; }
+
 template <int LOG2M>
 static hipError_t launch_row_pair(const LaunchArgs& a, void* dst, size_t nf, int A, float* mip) {
     using C = LdsCfg<LOG2M>;
@@ -812,9 +874,15 @@ static hipError_t launch_row_pair(const LaunchArgs& a, void* dst, size_t nf, int
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
         if (e0 != hipSuccess) return e0;                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * 8), lds_bytes, a.stream, static_cast<const float2*>(a.d_scratch), dst, nf, \
-                           A, twM, a.eps, a.shift);                                                              \
+                           A, twM, a.eps, a.epilogue >= EPI_BLU_MUL ? 0 : a.shift, epi_tab(a));                   \
     } while (0)
-    if (a.epilogue == EPI_LOGPSD) SDRK_ROWP(EPI_LOGPSD); else SDRK_ROWP(EPI_COMPLEX);
+    switch (a.epilogue) {
+        case EPI_LOGPSD: SDRK_ROWP(EPI_LOGPSD); break;
+        case EPI_BLU_MUL: SDRK_ROWP(EPI_BLU_MUL); break;
+        case EPI_BLU_POST_LOG: SDRK_ROWP(EPI_BLU_POST_LOG); break;
+        case EPI_BLU_POST_C64: SDRK_ROWP(EPI_BLU_POST_C64); break;
+        default: SDRK_ROWP(EPI_COMPLEX); break;
+    }
 #undef SDRK_ROWP
     return hipGetLastError();
 }
@@ -840,9 +908,15 @@ static hipError_t launch_row(const LaunchArgs& a, void* dst, size_t nf, int A, u
         hipError_t e0 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);              \
         if (e0 != hipSuccess) return e0;                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(C::T * ROWS), lds_bytes, a.stream, scratch, dst, nf, A, twM, a.eps, \
-                           a.shift);                                                                             \
+                           a.epilogue >= EPI_BLU_MUL ? 0 : a.shift, epi_tab(a));   /* EPI_BLU_*: the transform itself runs unshifted */ \
     } while (0)
-        if (a.epilogue == EPI_LOGPSD) SDRK_ROW(EPI_LOGPSD); else SDRK_ROW(EPI_COMPLEX);
+        switch (a.epilogue) {
+            case EPI_LOGPSD: SDRK_ROW(EPI_LOGPSD); break;
+            case EPI_BLU_MUL: SDRK_ROW(EPI_BLU_MUL); break;
+            case EPI_BLU_POST_LOG: SDRK_ROW(EPI_BLU_POST_LOG); break;
+            case EPI_BLU_POST_C64: SDRK_ROW(EPI_BLU_POST_C64); break;
+            default: SDRK_ROW(EPI_COMPLEX); break;
+        }
 #undef SDRK_ROW
         return hipGetLastError();
     }
@@ -854,7 +928,7 @@ static hipError_t launch_fft_tiled2_serial(const LaunchArgs& a) {
     if (!fft_tiled2_split(a.nfft, &la, &lm)) return hipErrorInvalidValue;
     const int A = 1 << la, M = 1 << lm;
     const float2* iq = static_cast<const float2*>(a.d_iq);
-    const size_t out_elem = a.epilogue == EPI_LOGPSD ? sizeof(float) : sizeof(float2);
+    const size_t out_elem = out_elem_bytes(a), out_row = out_row_elems(a);
     // workgroups per CU: LDS 136 B per point of A (or M); at most 2048 threads
     auto cap = [&](int L) {
         size_t per_cu = (160 * 1024) / ((size_t)136 * L);
@@ -886,7 +960,7 @@ static hipError_t launch_fft_tiled2_serial(const LaunchArgs& a) {
     for (size_t f0 = 0; f0 < a.n_frames; f0 += chunk) {
         const size_t nf = (a.n_frames - f0 < chunk) ? a.n_frames - f0 : chunk;
         const float2* src = iq + f0 * a.frame_stride;
-        void* dst = static_cast<char*>(a.d_out) + f0 * (size_t)a.nfft * out_elem;
+        void* dst = static_cast<char*>(a.d_out) + f0 * out_row * out_elem;
         hipError_t e;
         switch (la) {
             case 7: e = launch_col<7>(a, src, nf, M, cap(A)); break;
@@ -934,7 +1008,7 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
     if (!fft_tiled2_split(a.nfft, &la, &lm)) return hipErrorInvalidValue;
     const int A = 1 << la, M = 1 << lm;
     const float2* iq = static_cast<const float2*>(a.d_iq);
-    const size_t out_elem = a.epilogue == EPI_LOGPSD ? sizeof(float) : sizeof(float2);
+    const size_t out_elem = out_elem_bytes(a), out_row = out_row_elems(a);
     // Overlapped form: two role-sized grids resident together, two scratch halves.  Needs the second stream and
     // its events, and at least three half-chunks of work (otherwise nothing overlaps).
     const bool want_ovl = a.stream2 && a.ev_fork && a.col_cus > 0 && a.row_cus > 0;
@@ -991,7 +1065,7 @@ hipError_t launch_fft_tiled2(const LaunchArgs& a) {
             if (e != hipSuccess) return e;
             float* mip = (a.d_mip && fft_tiled2_has_mip(a.nfft, a.epilogue)) ? a.d_mip + f0 * (size_t)(a.nfft / 16) : nullptr;
             if (a.mip_written) *a.mip_written = mip != nullptr;
-            e = row_pass(ra, lm, static_cast<char*>(a.d_out) + f0 * (size_t)a.nfft * out_elem, nf, A, cap(M, rcus), cap(1024, rcus), mip);
+            e = row_pass(ra, lm, static_cast<char*>(a.d_out) + f0 * out_row * out_elem, nf, A, cap(M, rcus), cap(1024, rcus), mip);
             if (e == hipSuccess) e = hipEventRecord(a.ev_row[h], a.stream2);
             if (e != hipSuccess) return e;
         }

@@ -20,6 +20,11 @@ namespace sdrk {
 enum Epilogue : int {
     EPI_LOGPSD = 0,   // float32 20*log10(|X| + eps)          (streamer.py:121)
     EPI_COMPLEX = 1,  // complex64 X                           (streamer.py:119 only)
+    // The chirp-z transform of large frames that are not a power of two (bluestein.hip) runs its two multiplies on the stores of
+    // the inner transforms' row passes (fft_tiled2.hip) instead of as launches of their own — LaunchArgs::d_epi_tab, epi_n_out:
+    EPI_BLU_MUL = 2,       // complex64 conj(X[k] * tab[k]), natural order (shift must be 0): the filter multiply + conjugation
+    EPI_BLU_POST_LOG = 3,  // k < n_out only: y = conj(tab[k] X[k]) / nfft, stored at (k + n_out/2) mod n_out (or k), as dB,
+    EPI_BLU_POST_C64 = 4,  // ... or as complex64; rows of n_out values (the transform's own length is nfft >= 2 n_out - 1)
 };
 
 struct LaunchArgs {
@@ -50,6 +55,12 @@ struct LaunchArgs {
     // out (host, optional): set by the launcher that honoured d_mip — whoever reads the companion rows later trusts THIS, not
     // its own idea of which plans write them (a new row-pass variant or build switch cannot then make the two disagree)
     bool* mip_written = nullptr;
+    // EPI_BLU_*: the table the row pass multiplies by (filter spectrum: nfft entries; chirp: n_out entries) and the row length
+    const float2* d_epi_tab = nullptr;
+    int epi_n_out = 0;
+    // two-pass plans: samples that exist per input frame (0 = nfft).  The col pass clips its loads to them — the rest of the frame
+    // reads as zeros without touching memory (buffer bounds check): the zero padding of the chirp-z path's inner transforms
+    size_t in_valid = 0;
 };
 
 #ifdef __HIPCC__   // device helpers (the host-only sanitizer build of sdrk_api.hip, tests/fake_hip, compiles this header with g++)
@@ -109,8 +120,9 @@ bool blu_fused_supports(int M);
 hipError_t launch_blu_fused(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
                             const void* d_chirp, const void* d_bspec, const void* d_twM, float eps, int shift,
                             int epilogue, void* d_out, int num_cus, hipStream_t s);
+// compact: write only the N values of each frame (at stride M) and leave the padding to the reader's bounds check (in_valid)
 hipError_t launch_blu_pre(const void* d_iq, size_t frame_stride, size_t n_frames, int N, int M, const float* d_window,
-                          const void* d_chirp, void* d_a, int num_cus, hipStream_t s);
+                          const void* d_chirp, void* d_a, int num_cus, hipStream_t s, bool compact = false);
 hipError_t launch_blu_mul(const void* d_A, const void* d_B, size_t n_frames, int M, void* d_out, int num_cus,
                           hipStream_t s);
 hipError_t launch_blu_post(const void* d_Y, const void* d_chirp, size_t n_frames, int N, int M, float eps, int shift,

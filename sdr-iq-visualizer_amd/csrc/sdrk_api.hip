@@ -153,7 +153,6 @@ struct sdrk_plan {
     // N = 65536 fused path (fft_fused64k.hip).  fused64k: every launch (SDRK_PLAN_FUSED64K); fused_auto: launches of at least
     // FUSED_AUTO_MIN_FRAMES frames (the default for nfft = 65536), until one reports a failed hand-over (fused_broken, latched).
     bool fused64k = false, fused_auto = false, fused_broken = false;
-    bool num_cus_overridden = false;   // SDRK_NUM_CUS: the count no longer describes the device's XCDs -> no automatic fused launches
     void* d_fused_ring = nullptr;
     unsigned* d_fused_ctrl = nullptr;
     unsigned* h_fused_err = nullptr;   // pinned mailbox: error word of the last launches
@@ -263,19 +262,29 @@ FusedGate& fused_gate(int device) {
     return g;
 }
 
+// The chirp-z path's multiplies riding on an inner (power-of-two, two-pass) transform's row-pass stores: epilogue EPI_BLU_* with
+// this table, row length, and the OUTER plan's eps / shift (kernels.h).
+struct EpiArgs {
+    const float2* tab = nullptr;
+    int n_out = 0;
+    float eps = 0.0f;
+    int shift = 0;
+    size_t in_valid = 0;   // samples that exist per input frame (0 = all): LaunchArgs::in_valid
+};
+
 int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
-                     int epilogue, hipStream_t stream, float* d_mip, bool* mip_written);
+                     int epilogue, hipStream_t stream, float* d_mip, bool* mip_written, const EpiArgs* epi);
 
 // d_mip / mip_written: see LaunchArgs (kernels.h) — *mip_written tells whether the launch wrote the by-16 companion rows.
 int plan_launch(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
-                int epilogue, hipStream_t stream, float* d_mip = nullptr, bool* mip_written = nullptr) {
+                int epilogue, hipStream_t stream, float* d_mip = nullptr, bool* mip_written = nullptr, const EpiArgs* epi = nullptr) {
     RoctxRange range(p, n_frames, frame_stride, epilogue);
     if (mip_written) *mip_written = false;
-    return plan_launch_impl(p, d_iq, n_frames, frame_stride, d_out, epilogue, stream, d_mip, mip_written);
+    return plan_launch_impl(p, d_iq, n_frames, frame_stride, d_out, epilogue, stream, d_mip, mip_written, epi);
 }
 
 int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t frame_stride, void* d_out,
-                     int epilogue, hipStream_t stream, float* d_mip, bool* mip_written) {
+                     int epilogue, hipStream_t stream, float* d_mip, bool* mip_written, const EpiArgs* epi) {
     sdrk::LaunchArgs a;
     a.d_mip = d_mip;
     a.mip_written = mip_written;
@@ -294,6 +303,17 @@ int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t fra
     a.d_scratch = p->d_scratch;
     a.scratch_frames = p->scratch_frames;
     a.d_twiddle_2p = p->d_tw_2p;
+    if (epi) {
+        if (!p->tiled2 || p->stream2 || epilogue < sdrk::EPI_BLU_MUL)
+            return fail(SDRK_ERR_INVALID, "chirp-z epilogues need a serial two-pass inner plan");
+        a.d_epi_tab = epi->tab;
+        a.epi_n_out = epi->n_out;
+        a.eps = epi->eps;
+        a.shift = epi->shift;
+        a.in_valid = epi->in_valid;
+    } else if (epilogue >= sdrk::EPI_BLU_MUL) {
+        return fail(SDRK_ERR_INVALID, "epilogue %d needs its table", epilogue);
+    }
     if (p->col_cus > 0 && p->stream2) {
         a.stream2 = p->stream2;
         a.ev_fork = p->ev_fork;
@@ -315,9 +335,29 @@ int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t fra
                 if (e != hipSuccess) break;
                 continue;
             }
+            const bool fused_multiplies = p->blu_inner->tiled2 && !p->blu_inner->stream2;
+            // (the pre-multiply writes only the N values that exist; the first col pass reads the padding as zeros by bounds check)
             e = sdrk::launch_blu_pre(static_cast<const float2*>(d_iq) + f0 * frame_stride, frame_stride, nf, N, M,
-                                     p->d_window, p->d_blu_chirp, p->d_blu_a, p->num_cus, stream);
+                                     p->d_window, p->d_blu_chirp, p->d_blu_a, p->num_cus, stream, fused_multiplies);
             if (e != hipSuccess) break;
+            if (fused_multiplies) {
+                // five launches instead of seven (round 6): the filter multiply (+ conjugation) rides on the stores of the first
+                // inner transform's row pass, the post-multiply / crop to N / fftshift / log on the second one's, which writes the
+                // caller's rows directly (fft_tiled2.hip, EPI_BLU_*): 16 M + 8 M + 12 N bytes per frame fewer through the fabric
+                EpiArgs mul, post;
+                mul.tab = p->d_blu_bspec;
+                mul.in_valid = (size_t)N;
+                post.tab = p->d_blu_chirp;
+                post.n_out = N;
+                post.eps = p->eps;
+                post.shift = p->shift;
+                int st = plan_launch(p->blu_inner, p->d_blu_a, nf, (size_t)M, p->d_blu_b, sdrk::EPI_BLU_MUL, stream, nullptr, nullptr, &mul);
+                if (st != SDRK_OK) return st;
+                st = plan_launch(p->blu_inner, p->d_blu_b, nf, (size_t)M, static_cast<char*>(d_out) + f0 * (size_t)N * out_elem,
+                                 epilogue == sdrk::EPI_LOGPSD ? sdrk::EPI_BLU_POST_LOG : sdrk::EPI_BLU_POST_C64, stream, nullptr, nullptr, &post);
+                if (st != SDRK_OK) return st;
+                continue;
+            }
             int st = plan_launch(p->blu_inner, p->d_blu_a, nf, (size_t)M, p->d_blu_b, sdrk::EPI_COMPLEX, stream);
             if (st != SDRK_OK) return st;
             e = sdrk::launch_blu_mul(p->d_blu_b, p->d_blu_bspec, nf, M, p->d_blu_a, p->num_cus, stream);
@@ -334,7 +374,7 @@ int plan_launch_impl(sdrk_plan* p, const void* d_iq, size_t n_frames, size_t fra
         e = sdrk::launch_fft_lds(a);
     else if (p->nfft < 4096)
         e = sdrk::launch_fft_small(a);
-    else if (takes_fused(p, n_frames) && !d_mip) {
+    else if (takes_fused(p, n_frames) && !d_mip && epilogue <= sdrk::EPI_COMPLEX) {
         // The persistent grid needs every one of its workgroups resident at the same time; two such grids on two streams could
         // each hold part of the device and wait for the rest.  One at a time per device: each launch waits for the one before.
         FusedGate& gate = fused_gate(p->device);
@@ -363,7 +403,7 @@ RoctxRange::RoctxRange(const sdrk_plan* p, size_t n_frames, size_t stride, int e
     if (!r.push) return;
     char label[160];
     snprintf(label, sizeof label, "sdrk.plan_launch nfft=%d frames=%zu stride=%zu %s dev=%d", p->nfft, n_frames, stride,
-             epilogue == sdrk::EPI_LOGPSD ? "logpsd" : "complex", p->device);
+             epilogue == sdrk::EPI_LOGPSD ? "logpsd" : (epilogue == sdrk::EPI_COMPLEX ? "complex" : "chirp-z stage"), p->device);
     r.push(label);
     on = true;
 }
@@ -1047,7 +1087,7 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
     p->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* env = getenv("SDRK_NUM_CUS")) {   // size the persistent grids as for a smaller device (a partition
         long v = atol(env);                           // mode, or the tests of the grid-smaller-than-work paths); selects no kernel
-        if (v >= 1 && v < p->num_cus) { p->num_cus = (int)v; p->num_cus_overridden = true; }
+        if (v >= 1 && v < p->num_cus) p->num_cus = (int)v;
     }
 
 #define PLAN_TRY(expr)                                                                     \
@@ -1171,8 +1211,10 @@ int sdrk_plan_create_ex(int device, int nfft, size_t max_batch, int window_kind,
     // Single-launch, XCD-resident form of N = 65536 (fft_fused64k.hip); shares the tables of the tiled path.  Forced by
     // SDRK_PLAN_FUSED64K; otherwise the default for launches of FUSED_AUTO_MIN_FRAMES frames or more, unless SDRK_PLAN_TILED64K
     // or SDRK_PLAN_OVERLAP_PASSES asks for the two launches or the device's CUs do not make whole sets (32 workgroups per XCD).
+    // (A CU count that misdescribes the device — SDRK_NUM_CUS = 96 on eight XCDs — makes the first persistent launch fail its
+    // set formation; the plan then falls back for good, which is how the suite tests the fall-back.)
     const bool fused_auto = nfft == 65536 && !(flags & (SDRK_PLAN_FUSED64K | SDRK_PLAN_TILED64K | SDRK_PLAN_OVERLAP_PASSES)) &&
-                            p->num_cus >= 32 && p->num_cus % 32 == 0 && !p->num_cus_overridden;
+                            p->num_cus >= 32 && p->num_cus % 32 == 0;
     if ((flags & SDRK_PLAN_FUSED64K) || fused_auto) {
         p->fused64k = (flags & SDRK_PLAN_FUSED64K) != 0;
         p->fused_auto = fused_auto;

@@ -19,7 +19,9 @@ static hipError_t fake_transform(const LaunchArgs& a) {
             for (int k = 0; k < c.nfft; ++k) {
                 const float2 v = x[f * c.frame_stride + (size_t)k];
                 if (c.epilogue == EPI_LOGPSD) static_cast<float*>(c.d_out)[f * (size_t)c.nfft + k] = 3.0f * v.x - v.y + (float)(k & 1023);
-                else static_cast<float2*>(c.d_out)[f * (size_t)c.nfft + k] = make_float2(v.x + 1.0f, v.y - 1.0f);
+                else if (c.epilogue == EPI_BLU_POST_LOG) { if (k < c.epi_n_out) static_cast<float*>(c.d_out)[f * (size_t)c.epi_n_out + k] = v.x; }
+                else if (c.epilogue == EPI_BLU_POST_C64) { if (k < c.epi_n_out) static_cast<float2*>(c.d_out)[f * (size_t)c.epi_n_out + k] = v; }
+                else static_cast<float2*>(c.d_out)[f * (size_t)c.nfft + k] = make_float2(v.x + 1.0f, v.y - 1.0f);   // EPI_COMPLEX, EPI_BLU_MUL
             }
         if (c.d_mip && fft_tiled2_has_mip(c.nfft, c.epilogue)) {                 // by-16 max-hold, [band][km] as the row pass writes it
             const int M = 2048, A = c.nfft / M, bands = A / 16;
@@ -71,7 +73,7 @@ hipError_t launch_fused64k(const LaunchArgs& a, void*, unsigned* d_ctrl) {
 bool blu_fused_supports(int) { return false; }
 hipError_t launch_blu_fused(const void*, size_t, size_t, int, int, const float*, const void*, const void*, const void*, float,
                             int, int, void*, int, hipStream_t) { return hipErrorUnknown; }
-hipError_t launch_blu_pre(const void* d_iq, size_t stride, size_t nf, int N, int M, const float*, const void*, void* d_a, int, hipStream_t s) {
+hipError_t launch_blu_pre(const void* d_iq, size_t stride, size_t nf, int N, int M, const float*, const void*, void* d_a, int, hipStream_t s, bool) {
     fakehip::of(s).push([=] {
         for (size_t f = 0; f < nf; ++f) {
             float2* o = static_cast<float2*>(d_a) + f * (size_t)M;

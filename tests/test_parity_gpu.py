@@ -1758,6 +1758,47 @@ def test_persistent_grids_smaller_than_the_device(pkg, monkeypatch, cus):
             pf.spectrum_db(x)
 
 
+def test_default_plan_falls_back_after_a_failed_persistent_launch(pkg, monkeypatch):
+    """A default nfft = 65536 plan takes the persistent launch for calls of >= 512 frames; if that launch reports a failed
+    hand-over (here: SDRK_NUM_CUS = 96 misdescribes the eight-XCD device, so some sets of 32 workgroups never become complete —
+    what another process's long-running kernels would do to residency), the call must END with an error, never return rows
+    silently, and the plan must take the two tiled launches from then on: the same call repeated succeeds with the right rows."""
+    import ctypes
+    from sdr_iq_visualizer_amd import _ffi
+    from sdr_iq_visualizer_amd._ffi import SdrkError
+    from sdr_iq_visualizer_amd.spectrum import SpectrumPlan
+    lib = _ffi.lib()
+    n, rows, hop = 65536, 520, 32768
+    L = n + (rows - 1) * hop
+    d_in, d_a, d_b = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    _ffi.check(lib.sdrk_dev_alloc(0, ((L + 4095) // 4096) * 4096 * 8, ctypes.byref(d_in)))
+    _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_a)))
+    _ffi.check(lib.sdrk_dev_alloc(0, rows * n * 4, ctypes.byref(d_b)))
+    try:
+        _ffi.check(lib.sdrk_synth_fill(0, 21, 0, (L + 4095) // 4096, 4096, d_in, None))
+        with SpectrumPlan(n, window="hann", fused64k=False) as ref:
+            ref.exec_device(d_in.value, rows, d_b.value, frame_stride=hop)
+            ref.sync()
+        monkeypatch.setenv("SDRK_NUM_CUS", "96")
+        with SpectrumPlan(n, window="hann") as plan:
+            monkeypatch.delenv("SDRK_NUM_CUS")
+            with pytest.raises(SdrkError, match="sets formed|synchronisation"):
+                plan.exec_device(d_in.value, rows, d_a.value, frame_stride=hop)
+                plan.sync()
+            assert plan.fused_status() == {"launches": 1, "fallen_back": True}
+            plan.exec_device(d_in.value, rows, d_a.value, frame_stride=hop)      # the two tiled launches now (grid sized for 96 CUs)
+            plan.sync()
+            assert plan.fused_status() == {"launches": 1, "fallen_back": True}
+        a, b = np.empty(n, np.float32), np.empty(n, np.float32)
+        for r in (0, 1, rows // 2, rows - 1):
+            _ffi.check(lib.sdrk_memcpy_d2h(0, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_a.value + r * n * 4), n * 4))
+            _ffi.check(lib.sdrk_memcpy_d2h(0, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_b.value + r * n * 4), n * 4))
+            assert np.array_equal(a, b), r
+    finally:
+        for d in (d_in, d_a, d_b):
+            lib.sdrk_dev_free(0, d)
+
+
 # ---- resources --------------------------------------------------------------------------
 
 def test_plans_waterfalls_and_feature_calls_release_their_device_memory(pkg):
