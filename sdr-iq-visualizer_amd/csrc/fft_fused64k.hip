@@ -139,7 +139,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
     using C = LdsCfg<8>;
     constexpr int M = FU_A, T = C::T, D = FU_RING_SLOTS;   // T = 16 threads per 256-point transform
     extern __shared__ __attribute__((aligned(16))) float2 lds_all[];   // 16 x SLOT (exchange) / [256][17] transpose tile
-    __shared__ unsigned sh_role[3];
+    __shared__ unsigned sh_role[4];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
         sh_role[0] = g;
         sh_role[1] = member;
         sh_role[2] = xcc;
+        sh_role[3] = set;
     }
     __syncthreads();
     const unsigned g = sh_role[0], member = sh_role[1];
@@ -194,7 +195,18 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
     const int tr_sel = (g == 0 ? 0 : 32) + (int)member;
     unsigned* __restrict__ tr_base = reinterpret_cast<unsigned*>(static_cast<float*>(out_raw) + (size_t)n_frames * FU_N);
 #endif
-    const bool is_col = (FU_KNOCK & 1) ? true : (FU_KNOCK & 2) ? false : member < 16;
+#if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_ROLE_MIX)
+    // experiment: tickets are drawn in dispatch order, which walks the CUs of an XCD — so members 0..15 of EVERY set land on the
+    // same sixteen CUs.  Swapping the halves in every other set puts col and row workgroups on every CU.
+    const bool first_half_is_col = (sh_role[3] & 1u) == 0u;
+#else
+    const bool first_half_is_col = true;
+#endif
+    const bool is_col = (FU_KNOCK & 1) ? true : (FU_KNOCK & 2) ? false : ((member < 16) == first_half_is_col);
+#if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_PRIO)
+    // experiment: raise the issue priority of one role's waves (FU_PRIO = 1: col, 2: row)
+    if ((FU_PRIO == 1) == is_col) __builtin_amdgcn_s_setprio(2);
+#endif
     if (is_col) {
         // ---------------- col workgroup of tile position `pos` ----------------
         const int fr = tid & 15, tau = tid >> 4;
