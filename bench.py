@@ -340,8 +340,16 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
         try:
             _ffi.check(lib.sdrk_synth_fill(dev, 99, 0, gen_frames, 4096, d_gen, None))
             with SpectrumPlan(nfft, window=window, device=dev) as plan:
-                plan.exec_device(d_gen.value, n_frames, d_out.value, frame_stride=stride)
-                plan.sync()
+                try:
+                    plan.exec_device(d_gen.value, n_frames, d_out.value, frame_stride=stride)
+                    plan.sync()
+                except _ffi.SdrkError:
+                    # nfft = 65536: a persistent launch that could not get all its workgroups resident (a neighbour on the device)
+                    # reports a failed hand-over, and the plan takes the two tiled launches from then on — the leg goes on with those
+                    if not plan.fused_status()["fallen_back"]:
+                        raise
+                    plan.exec_device(d_gen.value, n_frames, d_out.value, frame_stride=stride)
+                    plan.sync()
                 probe, chosen, report = [], 0, None
                 if scratch_candidates > 1:
                     probe, chosen = plan.tune_scratch(d_gen.value, n_frames, d_out.value, scratch_candidates, frame_stride=stride)
@@ -349,6 +357,7 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
                 warm_up_by_time(lambda: plan.exec_device_timed(d_gen.value, n_frames, d_out.value, 1, frame_stride=stride))
                 ms = plan.exec_device_timed_each(d_gen.value, n_frames, d_out.value, reps, frame_stride=stride)
                 fused = plan.fused_status()
+                took_fused = bool(fused["launches"]) and not fused["fallen_back"]
             other = None
             if nfft == 65536:
                 # N = 65536 has two forms with bit-identical rows; the default plan above took one of them —
@@ -358,14 +367,14 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
                 keep = np.empty((len(picks), nfft), np.float32)
                 for i, r in enumerate(picks):
                     _ffi.check(lib.sdrk_memcpy_d2h(dev, keep[i].ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out.value + r * nfft * 4), nfft * 4))
-                with SpectrumPlan(nfft, window=window, device=dev, fused64k=not fused["launches"]) as alt:
+                with SpectrumPlan(nfft, window=window, device=dev, fused64k=not took_fused) as alt:
                     warm_up_by_time(lambda: alt.exec_device_timed(d_gen.value, n_frames, d_out.value, 1, frame_stride=stride))
                     ms_alt = alt.exec_device_timed_each(d_gen.value, n_frames, d_out.value, reps, frame_stride=stride)
                     alt.sync()
                 again = np.empty_like(keep)
                 for i, r in enumerate(picks):
                     _ffi.check(lib.sdrk_memcpy_d2h(dev, again[i].ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out.value + r * nfft * 4), nfft * 4))
-                other = {"form": "two tiled launches (fft_tiled2.hip)" if fused["launches"] else "one persistent launch (fft_fused64k.hip)",
+                other = {"form": "two tiled launches (fft_tiled2.hip)" if took_fused else "one persistent launch (fft_fused64k.hip)",
                          "ms": round(_median(ms_alt), 3), "ms_min": round(min(ms_alt), 3), "ms_max": round(max(ms_alt), 3),
                          "rows_identical_to_the_default_form": bool(np.array_equal(keep, again)), "rows_compared": picks}
         finally:
@@ -381,7 +390,7 @@ def device_config(lib, _ffi, SpectrumPlan, dev, nfft, n_frames, stride, window, 
             "algorithmic_bytes": algo, "algorithmic_formula": "8*L + 4*rows*N",
             "GBps": round(algo / t / 1e9, 1), "frac": round(algo / t / 1e9 / HBM_PEAK_GBPS, 4),
             **({} if nfft != 65536 else {
-                "form": "one persistent launch, intermediate in each XCD's L2 (fft_fused64k.hip)" if fused["launches"]
+                "form": "one persistent launch, intermediate in each XCD's L2 (fft_fused64k.hip)" if took_fused
                         else "two tiled launches (fft_tiled2.hip)",
                 "persistent_launches": fused["launches"], "fell_back_to_tiled": fused["fallen_back"], "other_form": other}),
             "warmup": "the plan's own transform for >= 100 ms before the timed launches (an idle device needs tens of ms of load "

@@ -1758,6 +1758,14 @@ def test_persistent_grids_smaller_than_the_device(pkg, monkeypatch, cus):
             pf.spectrum_db(x)
 
 
+def test_persistent_n65536_launch_random_workloads_equal_the_two_tiled_launches(pkg):
+    """tools/stress_fused64k.py with a fixed seed: 12 random device-resident workloads of 512 ... 1500 frames (packed, half-
+    overlapped and odd hops, four window kinds, both shifts, three eps, random first sample, 1-3 launches back to back) through the
+    default plan's persistent launch and through the two tiled launches: every value of every row identical."""
+    from tools import stress_fused64k
+    assert stress_fused64k.run(12, 6, max_frames=1500) == 12
+
+
 def test_default_plan_falls_back_after_a_failed_persistent_launch(pkg, monkeypatch):
     """A default nfft = 65536 plan takes the persistent launch for calls of >= 512 frames; if that launch reports a failed
     hand-over (here: SDRK_NUM_CUS = 96 misdescribes the eight-XCD device, so some sets of 32 workgroups never become complete —
