@@ -6,6 +6,7 @@
 #include "../../sdr-iq-visualizer_amd/csrc/kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <vector>
 
@@ -65,9 +66,13 @@ hipError_t launch_synth_fill(uint32_t seed, uint64_t first_frame, size_t n_frame
 size_t fused64k_ring_bytes() { return 4096; }
 size_t fused64k_ctrl_words() { return 64; }
 unsigned fused64k_sets(int) { return 1; }
+std::atomic<int> g_fake_fused_fail{0};   // the driver sets it: the next persistent launch reports a failed hand-over
+std::atomic<int> g_fake_fused_launches{0};
 hipError_t launch_fused64k(const LaunchArgs& a, void*, unsigned* d_ctrl) {
     hipError_t e = fake_transform(a);
-    fakehip::of(a.stream).push([d_ctrl] { memset(d_ctrl, 0, 64 * sizeof(unsigned)); d_ctrl[0] = 1; });   // "1 set formed", no error
+    const unsigned err = g_fake_fused_fail.exchange(0) ? 1u : 0u;
+    ++g_fake_fused_launches;
+    fakehip::of(a.stream).push([d_ctrl, err] { memset(d_ctrl, 0, 64 * sizeof(unsigned)); d_ctrl[0] = 1; d_ctrl[1] = err; });   // "1 set formed"
     return e;
 }
 bool blu_fused_supports(int) { return false; }

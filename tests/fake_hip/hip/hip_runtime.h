@@ -127,11 +127,14 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+namespace fakehip {
+inline int& cus() { static int c = 8; return c; }   // the stand-in device's CU count (a test may raise it: 32 = one whole XCD)
+}
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof *p);
     strcpy(p->name, "fake MI355X (host threads)");
     strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-");
-    p->multiProcessorCount = 8;
+    p->multiProcessorCount = fakehip::cus();
     p->totalGlobalMem = (size_t)64 << 30;
     p->clockRate = 2400000;
     return hipSuccess;

@@ -289,6 +289,71 @@ static void placement_and_misc() {
     CHECK(sdrk_host_link_probe(0, (size_t)4 << 20, &a, &b, &c) == SDRK_OK);
 }
 
+#include <hip/hip_runtime.h>   // the stand-in (tests/fake_hip): fakehip::cus()
+namespace sdrk { extern std::atomic<int> g_fake_fused_fail, g_fake_fused_launches; }
+
+// The default nfft = 65536 plan on a device whose CUs make whole sets: the persistent launch from 512 frames, the two tiled
+// launches below; a launch that reports a failed hand-over fails the call and latches the plan onto the two launches; two plans
+// on two streams (threads here) pass through the device-wide gate.
+static void fused_auto_policy() {
+    fakehip::cus() = 32;
+    const int n = 65536, nf = 512;
+    std::vector<c64> x((size_t)n + nf);                                   // frames at stride 1: 512 frames from 66 048 samples
+    fill(x, 77u);
+    void *dx = nullptr, *dr = nullptr;
+    CHECK(sdrk_dev_alloc(0, x.size() * sizeof(c64), &dx) == SDRK_OK && sdrk_dev_alloc(0, (size_t)nf * n * 4, &dr) == SDRK_OK);
+    CHECK(sdrk_memcpy_h2d(0, dx, x.data(), x.size() * sizeof(c64)) == SDRK_OK);
+    std::vector<float> rows((size_t)nf * n);
+    sdrk_plan *p = nullptr, *forced_tiled = nullptr;
+    CHECK(sdrk_plan_create(0, n, 1024, SDRK_WINDOW_RECT, nullptr, 1e-12f, 1, &p) == SDRK_OK);
+    CHECK(sdrk_plan_create_ex(0, n, 1024, SDRK_WINDOW_RECT, nullptr, 1e-12f, 1, SDRK_PLAN_TILED64K, &forced_tiled) == SDRK_OK);
+    sdrk_plan* bad = nullptr;
+    CHECK(sdrk_plan_create_ex(0, n, 8, 0, nullptr, 1e-12f, 1, SDRK_PLAN_TILED64K | SDRK_PLAN_FUSED64K, &bad) == SDRK_ERR_INVALID && !bad);
+    CHECK(sdrk_plan_create_ex(0, 4096, 8, 0, nullptr, 1e-12f, 1, SDRK_PLAN_TILED64K, &bad) == SDRK_ERR_INVALID && !bad);
+    unsigned launches = 99;
+    int fell = 9;
+    if (p && forced_tiled) {
+        const int before = sdrk::g_fake_fused_launches.load();
+        CHECK(sdrk_exec_device(p, dx, nf - 1, 1, static_cast<float*>(dr), nullptr) == SDRK_OK && sdrk_plan_sync(p) == SDRK_OK);
+        CHECK(sdrk_plan_fused_status(p, &launches, &fell) == SDRK_OK && launches == 0 && fell == 0);
+        CHECK(sdrk_exec_device(p, dx, nf, 1, static_cast<float*>(dr), nullptr) == SDRK_OK && sdrk_plan_sync(p) == SDRK_OK);
+        CHECK(sdrk_plan_fused_status(p, &launches, &fell) == SDRK_OK && launches == 1 && fell == 0);
+        CHECK(sdrk_memcpy_d2h(0, rows.data(), dr, rows.size() * 4) == SDRK_OK);
+        check_rows(x.data(), 1, rows.data(), nf, n);
+        CHECK(sdrk_exec_device(forced_tiled, dx, nf, 1, static_cast<float*>(dr), nullptr) == SDRK_OK && sdrk_plan_sync(forced_tiled) == SDRK_OK);
+        CHECK(sdrk_plan_fused_status(forced_tiled, &launches, &fell) == SDRK_OK && launches == 0 && fell == 0);
+        // two persistent launches from two threads on two plans: both pass the gate, both results right
+        {
+            void* dr2 = nullptr;
+            CHECK(sdrk_dev_alloc(0, (size_t)nf * n * 4, &dr2) == SDRK_OK);
+            sdrk_plan* p2 = nullptr;
+            CHECK(sdrk_plan_create(0, n, 1024, SDRK_WINDOW_RECT, nullptr, 1e-12f, 1, &p2) == SDRK_OK);
+            std::thread t([&] { CHECK(sdrk_exec_device(p2, dx, nf, 1, static_cast<float*>(dr2), nullptr) == SDRK_OK && sdrk_plan_sync(p2) == SDRK_OK); });
+            CHECK(sdrk_exec_device(p, dx, nf, 1, static_cast<float*>(dr), nullptr) == SDRK_OK && sdrk_plan_sync(p) == SDRK_OK);
+            t.join();
+            std::vector<float> rows2((size_t)nf * n);
+            CHECK(sdrk_memcpy_d2h(0, rows2.data(), dr2, rows2.size() * 4) == SDRK_OK);
+            check_rows(x.data(), 1, rows2.data(), nf, n);
+            CHECK(sdrk_dev_free(0, dr2) == SDRK_OK && sdrk_plan_destroy(p2) == SDRK_OK);
+        }
+        // a failed hand-over: the call fails, the plan falls back for good, the same call then succeeds through the two launches
+        sdrk::g_fake_fused_fail = 1;
+        const int st = sdrk_exec_device(p, dx, nf, 1, static_cast<float*>(dr), nullptr);
+        CHECK(st == SDRK_OK && sdrk_plan_sync(p) == SDRK_ERR_HIP);
+        CHECK(sdrk_plan_fused_status(p, &launches, &fell) == SDRK_OK && launches == 3 && fell == 1);
+        const int seen = sdrk::g_fake_fused_launches.load();
+        CHECK(sdrk_exec_device(p, dx, nf, 1, static_cast<float*>(dr), nullptr) == SDRK_OK && sdrk_plan_sync(p) == SDRK_OK);
+        CHECK(sdrk::g_fake_fused_launches.load() == seen && seen - before == 4);
+        CHECK(sdrk_plan_fused_status(p, &launches, &fell) == SDRK_OK && launches == 3 && fell == 1);
+        CHECK(sdrk_memcpy_d2h(0, rows.data(), dr, rows.size() * 4) == SDRK_OK);
+        check_rows(x.data(), 1, rows.data(), nf, n);
+    }
+    CHECK(sdrk_plan_fused_status(nullptr, &launches, &fell) == SDRK_ERR_INVALID);
+    CHECK(sdrk_plan_destroy(p) == SDRK_OK && sdrk_plan_destroy(forced_tiled) == SDRK_OK);
+    CHECK(sdrk_dev_free(0, dx) == SDRK_OK && sdrk_dev_free(0, dr) == SDRK_OK);
+    fakehip::cus() = 8;
+}
+
 int main(int argc, char** argv) {
     const int threads = argc > 1 ? atoi(argv[1]) : 3;
     const int rounds = argc > 2 ? atoi(argv[2]) : 1;
@@ -310,6 +375,7 @@ int main(int argc, char** argv) {
     for (auto& t : ts) t.join();
     waterfall_companion_rows();
     placement_and_misc();
+    fused_auto_policy();
     printf("bad=%d\n", g_bad.load());
     return g_bad.load() ? 1 : 0;
 }
