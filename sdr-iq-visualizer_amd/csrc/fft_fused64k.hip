@@ -35,7 +35,7 @@
 // L2.  No L2 write-back is needed because producer and consumer were verified, by XCC id, to share the L2.
 //
 // Measured (MI355X, round 6, profiles/r06/fused64k_policy.md): 4096 packed Hann frames 1.04 ms against 1.26 ms for the two
-// tiled launches; BASELINE config 3 (18 749 frames, hop 32768) 3.94 ms against 5.0 ms.  Rounds 1-5 had it at 2.2-2.4 ms /
+// tiled launches; BASELINE config 3 (18 749 frames, hop 32768) 3.83-3.94 ms against 4.98-5.04.  Rounds 1-5 had it at 2.2-2.4 ms /
 // 8.7 ms: the flags were agent-scope stores, which write through and DROP the line from the L2, so every poll went to the
 // fabric.  What the ring costs the fabric depends on how much of the L2 it takes (WRITE_SIZE per 4096 packed frames, 1.07 GB
 // of rows: 3 sets x 2 slots 3.38 GB, 3 x 1 1.50 GB, 1 x 2 with write-through row stores 1.10 GB) — but the kernel is not bound
