@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out
 LOG=gpurun_out/soak.log; : > $LOG
 for r in $(seq 0 $((R-1))); do
   seed=$((S + r))
-  for job in "stress_features.py 900" "stress_fused.py 500" "stress_host.py 120" "stress_waterfall.py 120" "stress_large.py 30"; do
+  for job in "stress_features.py 900" "stress_fused.py 500" "stress_host.py 120" "stress_waterfall.py 120" "stress_large.py 30" "stress_fused64k.py 150"; do
     set -- $job
     args="$2 $seed"
     t0=$(date +%s)
