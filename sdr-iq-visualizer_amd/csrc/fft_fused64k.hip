@@ -412,12 +412,13 @@ hipError_t launch_fused64k(const LaunchArgs& a, void* d_ring, unsigned* d_ctrl) 
     float2* ring = static_cast<float2*>(d_ring);
     const size_t lds_bytes = (size_t)16 * LdsCfg<8>::SLOT * sizeof(float2);   // 34,816 B (>= the [256][17] transpose tile)
     int sh = 16;
-    if (a.frame_stride % (size_t)FU_A == 0 && a.frame_stride / (size_t)FU_A == 128) sh = 8;
+    if (a.frame_stride % (size_t)FU_A == 0 && a.frame_stride / (size_t)FU_A == 128) sh = 8;    // 50 % overlap
+    if (a.frame_stride % (size_t)FU_A == 0 && a.frame_stride / (size_t)FU_A == 64) sh = 4;     // 75 % overlap
 #define SDRK_FU(W, E, S)                                                                                        \
     hipLaunchKernelGGL((fused64k_kernel<W, E, S>), dim3(grid), dim3(FU_THREADS), lds_bytes, a.stream, iq,         \
                        a.frame_stride, a.d_out, (unsigned)a.n_frames, a.d_window, twA, t1T, t2, ring, d_ctrl,     \
                        n_sets, sets_per_xcd, a.eps, a.shift)
-#define SDRK_FU2(W, E) do { if (sh == 8) SDRK_FU(W, E, 8); else SDRK_FU(W, E, 16); } while (0)
+#define SDRK_FU2(W, E) do { if (sh == 8) SDRK_FU(W, E, 8); else if (sh == 4) SDRK_FU(W, E, 4); else SDRK_FU(W, E, 16); } while (0)
 #ifdef SDRK_FUSED_EXPERIMENT
     if (a.epilogue == EPI_LOGPSD && a.d_window) {
         const int pin = fu_env("SDRK_FU_IN_AUX", 2), pout = fu_env("SDRK_FU_OUT_AUX", 2), nowait = fu_env("SDRK_FU_NOWAIT", 0);
