@@ -148,8 +148,20 @@ __global__ __launch_bounds__(FU_THREADS, 3) void fused64k_kernel(
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= FU_MAX_XCD - 1;
+#if defined(SDRK_FUSED_EXPERIMENT) && defined(FU_SEGREGATE)
+        // experiment: roles by CU instead of by arrival — the CUs of shader engines 0 and 2 host col workgroups only, those of
+        // 1 and 3 row workgroups only (HW_ID: CU bits 8-11, SE bits 13-15, workgroup slot bits 16-19; experiments/probes/
+        // hwid_probe.hip: 8 CUs per engine, 3 workgroups per CU), so that the L2-hit ring loads and polls of the row role never
+        // queue behind the input stream's HBM misses in their own CU's memory pipeline
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const bool col_cu = ((hw >> 13) & 1u) == 0u;
+        const unsigned r16 = __hip_atomic_fetch_add(ctrl + (col_cu ? 32 : 48) + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned set = r16 >> 4, member = (r16 & 15) + (col_cu ? 0u : 16u);
+#else
         const unsigned r = __hip_atomic_fetch_add(ctrl + 32 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned set = r >> 5, member = r & 31;
+#endif
         unsigned g = 0xFFFFFFFFu;
         if (set < sets_per_xcd && set < 8) {
             unsigned* slot = ctrl + 64 + xcc * 8 + set;
